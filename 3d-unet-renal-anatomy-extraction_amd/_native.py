@@ -1,0 +1,180 @@
+"""ctypes binding of libru3d.so (the C ABI declared in include/ru3d.h).
+
+There is NO fallback: if the shared library is missing the import fails loudly, and every op
+raises when handed a tensor that does not live on a HIP device.  PyTorch is used only for
+device memory, streams and autograd bookkeeping.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("RU3D_LIB", os.path.join(_HERE, "libru3d.so"))
+
+F32, BF16 = 0, 1
+LABEL_I64, LABEL_U8 = 0, 1
+ROLE_CONV_FWD, ROLE_CONV_DGRAD, ROLE_CONVT_FWD, ROLE_CONVT_DGRAD = 0, 1, 2, 3
+LOSS_HYBIRD, LOSS_DICELOSS, LOSS_FOCAL, LOSS_DICE = 0, 1, 2, 3
+MAX_CLASSES = 8
+
+
+class Tensor(ctypes.Structure):
+    """struct ru3d_tensor"""
+    _fields_ = [("ptr", ctypes.c_void_p), ("n", ctypes.c_int32), ("d", ctypes.c_int32), ("h", ctypes.c_int32),
+                ("w", ctypes.c_int32), ("c", ctypes.c_int32), ("ld", ctypes.c_int32)]
+
+
+_P = ctypes.POINTER(Tensor)
+_vp, _i, _i64, _f, _sz, _u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t,
+                                ctypes.c_uint64)
+
+# name -> (restype, argtypes): every symbol include/ru3d.h declares
+SIGNATURES = {
+    "ru3d_version": (_i, []),
+    "ru3d_last_error": (ctypes.c_char_p, []),
+    "ru3d_packed_weight_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "ru3d_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ru3d_conv3d_fwd": (_i, [_P, _vp, _vp, _P, _P, _i, _i, _i, _i, _vp]),
+    "ru3d_conv3d_dgrad": (_i, [_P, _vp, _P, _P, _i, _i, _i, _vp]),
+    "ru3d_conv3d_wgrad_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),
+    "ru3d_conv3d_wgrad": (_i, [_P, _P, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    "ru3d_convtranspose3d_k3s2p1_fwd": (_i, [_P, _vp, _vp, _P, _i, _vp]),
+    "ru3d_convtranspose3d_k3s2p1_dgrad": (_i, [_P, _vp, _P, _i, _vp]),
+    "ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes": (_sz, [_P, _P, _i]),
+    "ru3d_convtranspose3d_k3s2p1_wgrad": (_i, [_P, _P, _vp, _vp, _sz, _i, _vp]),
+    "ru3d_reduce_workspace_bytes": (_sz, [_P]),
+    "ru3d_instnorm_stats": (_i, [_P, _vp, _vp, _vp, _vp, _sz, _f, _i, _vp]),
+    "ru3d_in_lrelu_fwd": (_i, [_P, _vp, _vp, _P, _P, _f, _i, _vp]),
+    "ru3d_in_lrelu_bwd": (_i, [_P, _P, _P, _vp, _vp, _P, _P, _vp, _sz, _f, _i, _i, _vp]),
+    "ru3d_channel_sum": (_i, [_P, _vp, _vp, _sz, _i, _vp]),
+    "ru3d_dropout3d_scale": (_i, [_vp, _i, _f, _u64, _u64, _vp]),
+    "ru3d_copy_channels": (_i, [_P, _P, _i, _vp]),
+    "ru3d_add": (_i, [_P, _P, _P, _i, _vp]),
+    "ru3d_cast_f32": (_i, [_P, _P, _i, _vp]),
+    "ru3d_ncdhw_to_ndhwc": (_i, [_vp, _P, _i, _vp]),
+    "ru3d_ndhwc_to_ncdhw": (_i, [_P, _vp, _i, _vp]),
+    "ru3d_loss_state_bytes": (_sz, [_i]),
+    "ru3d_loss_workspace_bytes": (_sz, [_i, _i64, _i]),
+    "ru3d_loss_fwd": (_i, [_vp, _i64, _i64, _i64, _vp, _i, _i, _i64, _i, _i, _f, _vp, _f, _f, _f, _vp, _vp, _vp,
+                           _sz, _vp]),
+    "ru3d_loss_bwd": (_i, [_vp, _i64, _i64, _i64, _vp, _i, _i, _i64, _i, _f, _vp, _vp, _vp, _i, _vp]),
+    "ru3d_tversky": (_i, [_vp, _vp, _i64, _f, _f, _f, _vp, _vp, _sz, _vp]),
+    "ru3d_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libru3d.so not found at %s - build it with `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950). There is no non-HIP fallback for the 3D U-Net hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class Ru3dError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib.ru3d_last_error().decode("utf-8", "replace")
+        raise Ru3dError("ru3d %s failed (status %d): %s" % (what, rc, msg))
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise Ru3dError("ru3d: unsupported storage dtype %s (float32 or bfloat16)" % dt)
+
+
+def require_device(t, what="tensor"):
+    if not t.is_cuda:
+        raise Ru3dError("ru3d: %s lives on %s; the MI355X-native path has no CPU fallback - move the model "
+                        "and its inputs to a HIP device (.cuda())" % (what, t.device))
+
+
+# --------------------------------------------------------------------------- activations
+def new_act(n, c, d, h, w, dtype, device, zero=False):
+    """[N,C,D,H,W]-shaped tensor whose memory is NDHWC (torch.channels_last_3d strides)."""
+    buf = (torch.zeros if zero else torch.empty)((n, d, h, w, c), dtype=dtype, device=device)
+    return buf.permute(0, 4, 1, 2, 3)
+
+
+def is_ndhwc(t):
+    """True when t ([N,C,D,H,W]) is dense NDHWC with an optional channel pitch (a channel slice)."""
+    if t.dim() != 5:
+        return False
+    n, c, d, h, w = t.shape
+    sn, sc, sd, sh, sw = t.stride()
+    if c > 1 and sc != 1:
+        return False
+    ld = None
+    for size, stride, inner in ((w, sw, 1), (h, sh, w), (d, sd, h * w), (n, sn, d * h * w)):
+        if size > 1:
+            if stride % inner != 0:
+                return False
+            cand = stride // inner
+            if ld is None:
+                ld = cand
+            elif cand != ld:
+                return False
+    return ld is None or ld >= c
+
+
+def to_ndhwc(t):
+    """Plumbing: make an arbitrary [N,C,D,H,W] tensor dense NDHWC (no copy when it already is)."""
+    if is_ndhwc(t):
+        return t
+    return t.contiguous(memory_format=torch.channels_last_3d)
+
+
+def desc(t):
+    """ru3d_tensor descriptor of an NDHWC-strided [N,C,D,H,W] torch tensor."""
+    require_device(t)
+    if not is_ndhwc(t):
+        raise Ru3dError("ru3d: tensor of shape %s / strides %s is not NDHWC" % (tuple(t.shape), t.stride()))
+    n, c, d, h, w = t.shape
+    ld = c
+    for size, stride, inner in ((w, t.stride(4), 1), (h, t.stride(3), w), (d, t.stride(2), h * w),
+                                (n, t.stride(0), d * h * w)):
+        if size > 1:
+            ld = stride // inner
+            break
+    return Tensor(t.data_ptr(), n, d, h, w, c, ld)
+
+
+def ref(d):
+    return ctypes.byref(d) if d is not None else None
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# --------------------------------------------------------------------------- workspace
+_WS = {}
+
+
+def workspace(nbytes, device):
+    """One growing scratch buffer per (device, stream): every kernel that uses it runs in-order on that stream."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf

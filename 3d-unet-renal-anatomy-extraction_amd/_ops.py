@@ -1,0 +1,391 @@
+"""Host-side wrappers over the C ABI (one Python function per entry point) and the autograd
+Functions that stitch them into the reference's blocks.  No arithmetic happens here: every
+tensor value is produced by a HIP kernel of libru3d.so; torch supplies memory and the tape.
+"""
+import ctypes
+import threading
+
+import torch
+
+import _native as N
+from _native import check, desc, ptr, ref, stream
+
+LRELU_SLOPE = 0.01   # nn.LeakyReLU default negative_slope (reference network.py:386)
+IN_EPS = 1e-5        # nn.InstanceNorm3d default eps (reference network.py:384)
+
+
+# --------------------------------------------------------------------------- thin wrappers
+def pack_weight(w, role, dtype):
+    """w: fp32 parameter in the reference layout (Conv3d [Cout,Cin,k,k,k]; ConvTranspose3d [Cin,Cout,k,k,k])."""
+    N.require_device(w, "weight")
+    w = w.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    k = w.shape[2]
+    if role in (N.ROLE_CONVT_FWD, N.ROLE_CONVT_DGRAD):
+        cin, cout = w.shape[0], w.shape[1]
+    else:
+        cout, cin = w.shape[0], w.shape[1]
+    code = N.dtype_code(dtype)
+    nbytes = N.lib.ru3d_packed_weight_bytes(cout, cin, k, role, code)
+    if nbytes == 0:
+        raise N.Ru3dError("ru3d: cannot pack weight of shape %s" % (tuple(w.shape),))
+    out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    check(N.lib.ru3d_pack_weight(ptr(w), ptr(out), cout, cin, k, role, code, stream()), "pack_weight")
+    return out
+
+
+def _bias(b):
+    if b is None:
+        return None
+    b = b.detach()
+    return b if (b.dtype == torch.float32 and b.is_contiguous()) else b.float().contiguous()
+
+
+def _conv_out(size, k, s):
+    return (size + 2 * (k // 2) - k) // s + 1
+
+
+def conv_fwd(x, pw, bias, cout, k, stride, res=None, out_dtype=None):
+    n, _, d, h, w = x.shape
+    out_dtype = out_dtype or x.dtype
+    y = N.new_act(n, cout, _conv_out(d, k, stride), _conv_out(h, k, stride), _conv_out(w, k, stride), out_dtype,
+                  x.device)
+    b = _bias(bias)
+    dx, dyy = desc(x), desc(y)
+    dr = desc(res) if res is not None else None
+    check(N.lib.ru3d_conv3d_fwd(ref(dx), ptr(pw), ptr(b), ref(dr), ref(dyy), k, stride, N.dtype_code(x.dtype),
+                                N.dtype_code(out_dtype), stream()), "conv3d_fwd")
+    return y
+
+
+def conv_dgrad(dy, pw, in_shape, k, stride, res=None):
+    n, cin, d, h, w = in_shape
+    dx = N.new_act(n, cin, d, h, w, dy.dtype, dy.device)
+    ddy, ddx = desc(dy), desc(dx)
+    dr = desc(res) if res is not None else None
+    check(N.lib.ru3d_conv3d_dgrad(ref(ddy), ptr(pw), ref(dr), ref(ddx), k, stride, N.dtype_code(dy.dtype), stream()),
+          "conv3d_dgrad")
+    return dx
+
+
+def conv_wgrad(x, dy, k, stride):
+    cout, cin = dy.shape[1], x.shape[1]
+    dw = torch.empty((cout, cin, k, k, k), dtype=torch.float32, device=x.device)
+    dx, ddy = desc(x), desc(dy)
+    code = N.dtype_code(x.dtype)
+    nbytes = N.lib.ru3d_conv3d_wgrad_workspace_bytes(ref(dx), ref(ddy), k, stride, code)
+    ws = N.workspace(nbytes, x.device)
+    check(N.lib.ru3d_conv3d_wgrad(ref(dx), ref(ddy), ptr(dw), ptr(ws), ws.numel(), k, stride, code, stream()),
+          "conv3d_wgrad")
+    return dw
+
+
+def convt_fwd(x, pw, bias, cout):
+    n, _, d, h, w = x.shape
+    y = N.new_act(n, cout, 2 * d, 2 * h, 2 * w, x.dtype, x.device)
+    b = _bias(bias)
+    dx, dyy = desc(x), desc(y)
+    check(N.lib.ru3d_convtranspose3d_k3s2p1_fwd(ref(dx), ptr(pw), ptr(b), ref(dyy), N.dtype_code(x.dtype), stream()),
+          "convtranspose3d_fwd")
+    return y
+
+
+def convt_dgrad(dy, pw, in_shape):
+    n, cin, d, h, w = in_shape
+    dx = N.new_act(n, cin, d, h, w, dy.dtype, dy.device)
+    ddy, ddx = desc(dy), desc(dx)
+    check(N.lib.ru3d_convtranspose3d_k3s2p1_dgrad(ref(ddy), ptr(pw), ref(ddx), N.dtype_code(dy.dtype), stream()),
+          "convtranspose3d_dgrad")
+    return dx
+
+
+def convt_wgrad(x, dy):
+    cin, cout = x.shape[1], dy.shape[1]
+    dw = torch.empty((cin, cout, 3, 3, 3), dtype=torch.float32, device=x.device)
+    dx, ddy = desc(x), desc(dy)
+    code = N.dtype_code(x.dtype)
+    nbytes = N.lib.ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes(ref(dx), ref(ddy), code)
+    ws = N.workspace(nbytes, x.device)
+    check(N.lib.ru3d_convtranspose3d_k3s2p1_wgrad(ref(dx), ref(ddy), ptr(dw), ptr(ws), ws.numel(), code, stream()),
+          "convtranspose3d_wgrad")
+    return dw
+
+
+def in_stats(y, drop_scale=None):
+    n, c = y.shape[0], y.shape[1]
+    mean = torch.empty(n * c, dtype=torch.float32, device=y.device)
+    scale = torch.empty(n * c, dtype=torch.float32, device=y.device)
+    dy = desc(y)
+    ws = N.workspace(N.lib.ru3d_reduce_workspace_bytes(ref(dy)), y.device)
+    check(N.lib.ru3d_instnorm_stats(ref(dy), ptr(drop_scale), ptr(mean), ptr(scale), ptr(ws), ws.numel(), IN_EPS,
+                                    N.dtype_code(y.dtype), stream()), "instnorm_stats")
+    return mean, scale
+
+
+def in_lrelu_fwd(y, mean, scale, res=None, out=None):
+    if out is None:
+        n, c, d, h, w = y.shape
+        out = N.new_act(n, c, d, h, w, y.dtype, y.device)
+    dy, do = desc(y), desc(out)
+    dr = desc(res) if res is not None else None
+    check(N.lib.ru3d_in_lrelu_fwd(ref(dy), ptr(mean), ptr(scale), ref(dr), ref(do), LRELU_SLOPE,
+                                  N.dtype_code(y.dtype), stream()), "in_lrelu_fwd")
+    return out
+
+
+def in_lrelu_bwd(gout, out, y, mean, scale, want_gpre=False, zero_far=False):
+    n, c, d, h, w = y.shape
+    dy = N.new_act(n, c, d, h, w, y.dtype, y.device)
+    gpre = N.new_act(n, c, d, h, w, y.dtype, y.device) if want_gpre else None
+    dg, do, dyy, ddy = desc(gout), desc(out), desc(y), desc(dy)
+    dp = desc(gpre) if want_gpre else None
+    ws = N.workspace(N.lib.ru3d_reduce_workspace_bytes(ref(dyy)), y.device)
+    check(N.lib.ru3d_in_lrelu_bwd(ref(dg), ref(do), ref(dyy), ptr(mean), ptr(scale), ref(ddy), ref(dp), ptr(ws),
+                                  ws.numel(), LRELU_SLOPE, 1 if zero_far else 0, N.dtype_code(y.dtype), stream()),
+          "in_lrelu_bwd")
+    return dy, gpre
+
+
+def channel_sum(t):
+    out = torch.empty(t.shape[1], dtype=torch.float32, device=t.device)
+    dt = desc(t)
+    ws = N.workspace(N.lib.ru3d_reduce_workspace_bytes(ref(dt)), t.device)
+    check(N.lib.ru3d_channel_sum(ref(dt), ptr(out), ptr(ws), ws.numel(), N.dtype_code(t.dtype), stream()),
+          "channel_sum")
+    return out
+
+
+def copy_channels(src, dst):
+    ds, dd = desc(src), desc(dst)
+    check(N.lib.ru3d_copy_channels(ref(ds), ref(dd), N.dtype_code(src.dtype), stream()), "copy_channels")
+
+
+def add(a, b):
+    n, c, d, h, w = a.shape
+    out = N.new_act(n, c, d, h, w, a.dtype, a.device)
+    da, db, do = desc(a), desc(b), desc(out)
+    check(N.lib.ru3d_add(ref(da), ref(db), ref(do), N.dtype_code(a.dtype), stream()), "add")
+    return out
+
+
+def cast_f32(src, dtype):
+    """fp32 NDHWC tensor -> storage dtype (no-op for fp32)."""
+    if dtype == torch.float32:
+        return src
+    n, c, d, h, w = src.shape
+    out = N.new_act(n, c, d, h, w, dtype, src.device)
+    ds, do = desc(src), desc(out)
+    check(N.lib.ru3d_cast_f32(ref(ds), ref(do), N.dtype_code(dtype), stream()), "cast_f32")
+    return out
+
+
+def ncdhw_to_ndhwc(x, dtype):
+    """fp32 NCDHW-contiguous [N,C,D,H,W] -> NDHWC tensor of `dtype` (the only layout change on the path)."""
+    N.require_device(x, "input")
+    x = x.detach()
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        x = x.float().contiguous()
+    n, c, d, h, w = x.shape
+    out = N.new_act(n, c, d, h, w, dtype, x.device)
+    do = desc(out)
+    check(N.lib.ru3d_ncdhw_to_ndhwc(ptr(x), ref(do), N.dtype_code(dtype), stream()), "ncdhw_to_ndhwc")
+    return out
+
+
+def ndhwc_to_ncdhw(x):
+    n, c, d, h, w = x.shape
+    out = torch.empty((n, c, d, h, w), dtype=torch.float32, device=x.device)
+    dx = desc(x)
+    check(N.lib.ru3d_ndhwc_to_ncdhw(ref(dx), ptr(out), N.dtype_code(x.dtype), stream()), "ndhwc_to_ncdhw")
+    return out
+
+
+_drop_lock = threading.Lock()
+_drop_counter = [0]
+
+
+def dropout_scale(n, c, p, device):
+    """Per-(n,c) Dropout3d factor (0 or 1/(1-p)) from the on-device counter-based generator."""
+    with _drop_lock:
+        offset = _drop_counter[0]
+        _drop_counter[0] += n * c
+    out = torch.empty(n * c, dtype=torch.float32, device=device)
+    seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+    check(N.lib.ru3d_dropout3d_scale(ptr(out), n * c, float(p), ctypes.c_uint64(seed), ctypes.c_uint64(offset),
+                                     stream()), "dropout3d_scale")
+    return out
+
+
+def as_input(x, dtype):
+    """Bring a user tensor onto the native path: NDHWC memory in the storage dtype.  C == 1 inputs in the
+    reference's NCDHW layout are already NDHWC; anything else goes through the repack kernel."""
+    N.require_device(x, "input")
+    if x.dim() != 5:
+        raise N.Ru3dError("ru3d: expected a 5-D [N,C,D,H,W] tensor, got %s" % (tuple(x.shape),))
+    if x.dtype == dtype and N.is_ndhwc(x):
+        return x
+    if N.is_ndhwc(x) and x.dtype == torch.float32:
+        return cast_f32(x, dtype)
+    if x.is_contiguous() or x.dtype != torch.float32:
+        return ncdhw_to_ndhwc(x, dtype)
+    return ncdhw_to_ndhwc(x.contiguous(), dtype)
+
+
+def as_grad(g, like_dtype):
+    """Gradient tensors arriving from autograd: make them NDHWC in the storage dtype (plumbing only)."""
+    if g.dtype != like_dtype:
+        if g.dtype == torch.float32 and N.is_ndhwc(g):
+            return cast_f32(g, like_dtype)
+        g = g.to(like_dtype)
+    return N.to_ndhwc(g)
+
+
+# --------------------------------------------------------------------------- autograd: plain conv (stem / head / skip)
+class ConvFn(torch.autograd.Function):
+    """nn.Conv3d(k in {1,3}, stride in {1,2}, padding=k//2) with bias: reference network.py:541-547 (stem, head)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, storage_dtype, out_dtype):
+        xin = as_input(x, storage_dtype)
+        k = weight.shape[2]
+        pw = pack_weight(weight, N.ROLE_CONV_FWD, storage_dtype)
+        y = conv_fwd(xin, pw, bias, weight.shape[0], k, stride, out_dtype=out_dtype)
+        ctx.save_for_backward(xin, weight)
+        ctx.stride, ctx.k, ctx.has_bias = stride, k, bias is not None
+        ctx.storage_dtype = storage_dtype
+        ctx.in_dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        xin, weight = ctx.saved_tensors
+        sd = ctx.storage_dtype
+        gy = as_grad(gy, sd)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[1]:
+            gw = conv_wgrad(xin, gy, ctx.k, ctx.stride)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = channel_sum(gy)
+        if ctx.needs_input_grad[0]:
+            pwd = pack_weight(weight, N.ROLE_CONV_DGRAD, sd)
+            gx = conv_dgrad(gy, pwd, tuple(xin.shape), ctx.k, ctx.stride)
+            if gx.dtype != ctx.in_dtype:
+                gx = gx.to(ctx.in_dtype)
+        return gx, gw, gb, None, None, None
+
+
+# --------------------------------------------------------------------------- autograd: ResBlock
+class ResBlockFn(torch.autograd.Function):
+    """reference network.py:405-416:
+        skip = skip_conv(x) if (in != out or stride != 1) else x
+        x = conv1(x); x = dropout(x); x = lrelu(IN(x)); x = conv2(x); return lrelu(IN(x) + skip)
+    """
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, ws, bs, stride, drop_scale):
+        sd = x.dtype
+        x = N.to_ndhwc(x)
+        cout = w1.shape[0]
+        pw1 = pack_weight(w1, N.ROLE_CONV_FWD, sd)
+        y1 = conv_fwd(x, pw1, b1, cout, 3, stride)
+        mean1, scale1 = in_stats(y1, drop_scale)
+        a1 = in_lrelu_fwd(y1, mean1, scale1)
+        pw2 = pack_weight(w2, N.ROLE_CONV_FWD, sd)
+        y2 = conv_fwd(a1, pw2, b2, cout, 3, 1)
+        mean2, scale2 = in_stats(y2)
+        if ws is not None:
+            pws = pack_weight(ws, N.ROLE_CONV_FWD, sd)
+            skip = conv_fwd(x, pws, bs, cout, 1, stride)
+        else:
+            skip = x
+        z = in_lrelu_fwd(y2, mean2, scale2, res=skip)
+        ctx.save_for_backward(x, y1, a1, y2, z, mean1, scale1, mean2, scale2, w1, w2, ws)
+        ctx.stride = stride
+        ctx.has_skip_conv = ws is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, y1, a1, y2, z, mean1, scale1, mean2, scale2, w1, w2, ws = ctx.saved_tensors
+        sd = x.dtype
+        stride = ctx.stride
+        gz = as_grad(gz, sd)
+        # lrelu(IN(y2) + skip): dy2 and the pre-activation gradient (= d/dskip)
+        dy2, gpre = in_lrelu_bwd(gz, z, y2, mean2, scale2, want_gpre=True)
+        gw2 = conv_wgrad(a1, dy2, 3, 1)
+        gb2 = torch.zeros(w2.shape[0], dtype=torch.float32, device=x.device)  # bias before IN: gradient == 0
+        pw2d = pack_weight(w2, N.ROLE_CONV_DGRAD, sd)
+        da1 = conv_dgrad(dy2, pw2d, tuple(a1.shape), 3, 1)
+        dy1, _ = in_lrelu_bwd(da1, a1, y1, mean1, scale1)
+        gw1 = conv_wgrad(x, dy1, 3, stride)
+        gb1 = torch.zeros(w1.shape[0], dtype=torch.float32, device=x.device)
+        gws = gbs = None
+        gx = None
+        need_gx = ctx.needs_input_grad[0]
+        if ctx.has_skip_conv:
+            gws = conv_wgrad(x, gpre, 1, stride)
+            gbs = channel_sum(gpre)
+            if need_gx:
+                pwsd = pack_weight(ws, N.ROLE_CONV_DGRAD, sd)
+                gx0 = conv_dgrad(gpre, pwsd, tuple(x.shape), 1, stride)
+                pw1d = pack_weight(w1, N.ROLE_CONV_DGRAD, sd)
+                gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gx0)
+        elif need_gx:
+            pw1d = pack_weight(w1, N.ROLE_CONV_DGRAD, sd)
+            gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gpre)
+        return gx, gw1, gb1, gw2, gb2, gws, gbs, None, None
+
+
+# --------------------------------------------------------------------------- autograd: ConvTrans3D (+ concat)
+class UpFn(torch.autograd.Function):
+    """reference network.py:311-317 (+ :346-350 when `skip` is given):
+        u = lrelu(IN(pad_far(convT_k3s2p1(x))));  return cat((u, skip), dim=1)
+    The concat is written in place: the IN+LeakyReLU kernel stores into the first channels of the
+    output buffer, a channel-slice copy fills the rest.
+    """
+
+    @staticmethod
+    def forward(ctx, x, wt, bt, skip):
+        sd = x.dtype
+        x = N.to_ndhwc(x)
+        cout = wt.shape[1]
+        pw = pack_weight(wt, N.ROLE_CONVT_FWD, sd)
+        y = convt_fwd(x, pw, bt, cout)
+        mean, scale = in_stats(y)
+        n, _, d, h, w = y.shape
+        if skip is not None:
+            skip = as_grad(skip, sd)
+            cs = skip.shape[1]
+            if tuple(skip.shape[2:]) != (d, h, w) or skip.shape[0] != n:
+                raise N.Ru3dError("UpConcat: skip %s does not match up-sampled %s" % (tuple(skip.shape), tuple(y.shape)))
+            buf = N.new_act(n, cout + cs, d, h, w, sd, x.device)
+            u = buf[:, :cout]
+            in_lrelu_fwd(y, mean, scale, out=u)
+            copy_channels(skip, buf[:, cout:])
+            out = buf
+        else:
+            u = in_lrelu_fwd(y, mean, scale)
+            out = u
+        ctx.save_for_backward(x, y, out, mean, scale, wt)
+        ctx.cout = cout
+        ctx.has_skip = skip is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, out, mean, scale, wt = ctx.saved_tensors
+        sd = x.dtype
+        g = as_grad(g, sd)
+        cout = ctx.cout
+        u = out[:, :cout] if ctx.has_skip else out
+        gu = g[:, :cout] if ctx.has_skip else g
+        gskip = g[:, cout:] if ctx.has_skip else None
+        dy, _ = in_lrelu_bwd(gu, u, y, mean, scale, zero_far=True)
+        gw = convt_wgrad(x, dy)
+        gb = channel_sum(dy)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            pwd = pack_weight(wt, N.ROLE_CONVT_DGRAD, sd)
+            gx = convt_dgrad(dy, pwd, tuple(x.shape))
+        return gx, gw, gb, gskip

@@ -1,0 +1,203 @@
+// C-ABI entry points for the convolution family + error plumbing.  Validates shapes on the host
+// before anything is launched (a faulting kernel can reset the whole GPU node), builds the
+// data-movement geometry and dispatches to the MFMA implicit-GEMM kernels (bf16, MFMA-friendly
+// channel counts) or to the generic direct kernels (fp32 parity mode, odd channel counts).
+#include "common.h"
+#include "conv.h"
+#include <string>
+
+static thread_local std::string g_last_error;
+
+int ru3d_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+int ru3d_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ru3d_fail((int)e, "%s: %s", what, hipGetErrorString(e));
+        return (int)e > 0 ? (int)e : 1;
+    }
+    return 0;
+}
+
+extern "C" int ru3d_version(void) { return RU3D_VERSION; }
+extern "C" const char* ru3d_last_error(void) { return g_last_error.c_str(); }
+
+static bool dtype_ok(int d) { return d == RU3D_F32 || d == RU3D_BF16; }
+static int conv_out(int in, int k, int s) { return (in + 2 * (k / 2) - k) / s + 1; }
+
+// channels (in', out') of the data-movement kernel that consumes a packed weight
+static void role_channels(int cout, int cin, int role, int* kin, int* kout, int64_t* s_o, int64_t* s_i, int taps) {
+    switch (role) {
+        case RU3D_ROLE_CONV_FWD:  // W[co][ci][tap]
+            *kin = cin; *kout = cout; *s_o = (int64_t)cin * taps; *s_i = taps; break;
+        case RU3D_ROLE_CONV_DGRAD:  // in' = co, out' = ci
+            *kin = cout; *kout = cin; *s_o = taps; *s_i = (int64_t)cin * taps; break;
+        case RU3D_ROLE_CONVT_FWD:  // W[ci][co][tap], in' = ci, out' = co
+            *kin = cin; *kout = cout; *s_o = taps; *s_i = (int64_t)cout * taps; break;
+        default:  // CONVT_DGRAD: in' = co, out' = ci
+            *kin = cout; *kout = cin; *s_o = (int64_t)cout * taps; *s_i = taps; break;
+    }
+}
+
+extern "C" size_t ru3d_packed_weight_bytes(int cout, int cin, int k, int role, int dtype) {
+    if (cout <= 0 || cin <= 0 || (k != 1 && k != 3) || role < 0 || role > 3 || !dtype_ok(dtype)) return 0;
+    const int taps = k * k * k;
+    int kin, kout;
+    int64_t s_o, s_i;
+    role_channels(cout, cin, role, &kin, &kout, &s_o, &s_i, taps);
+    if (mfma_conv_eligible(kin, kout, k, dtype, dtype)) return mfma_packed_bytes(kin, kout, taps);
+    return (size_t)taps * kin * generic_cout_pad(kout) * (dtype == RU3D_F32 ? 4 : 2);
+}
+
+extern "C" int ru3d_pack_weight(const float* src, void* dst, int cout, int cin, int k, int role, int dtype,
+                                void* stream) {
+    RU3D_REQUIRE(src && dst, "pack_weight: null pointer");
+    RU3D_REQUIRE(cout > 0 && cin > 0 && (k == 1 || k == 3), "pack_weight: bad shape cout=%d cin=%d k=%d", cout, cin, k);
+    RU3D_REQUIRE(role >= 0 && role <= 3 && dtype_ok(dtype), "pack_weight: bad role/dtype");
+    const int taps = k * k * k;
+    int kin, kout;
+    int64_t s_o, s_i;
+    role_channels(cout, cin, role, &kin, &kout, &s_o, &s_i, taps);
+    if (mfma_conv_eligible(kin, kout, k, dtype, dtype))
+        return pack_mfma_launch(src, dst, kin, kout, taps, s_o, s_i, 0, as_stream(stream));
+    return pack_generic_launch(src, dst, kin, kout, taps, s_o, s_i, 0, dtype, as_stream(stream));
+}
+
+static int run_conv(const ru3d_tensor* x, const void* w, const float* bias, const ru3d_tensor* res,
+                    const ru3d_tensor* y, int k, int stride, int transposed, int flip, int zero_far, int dtype,
+                    int y_dtype, hipStream_t st) {
+    ConvGeom g;
+    g.N = x->n;
+    g.Di = x->d; g.Hi = x->h; g.Wi = x->w; g.Cin = x->c; g.ldx = x->ld;
+    g.Do = y->d; g.Ho = y->h; g.Wo = y->w; g.Cout = y->c; g.ldy = y->ld;
+    g.CoutPad = generic_cout_pad(y->c);
+    g.ldr = res ? res->ld : 0;
+    g.k = k; g.stride = stride; g.pad = k / 2;
+    g.transposed = transposed; g.zero_far = zero_far; g.flip = flip;
+    if (mfma_conv_eligible(g.Cin, g.Cout, k, dtype, y_dtype))
+        return conv_mfma_launch(x->ptr, w, bias, res ? res->ptr : nullptr, y->ptr, g, st);
+    return conv_generic_launch(x->ptr, w, bias, res ? res->ptr : nullptr, y->ptr, g, dtype, y_dtype, st);
+}
+
+static bool res_ok(const ru3d_tensor* res, const ru3d_tensor* y) {
+    return !res || (tensor_ok(res) && res->n == y->n && res->d == y->d && res->h == y->h && res->w == y->w &&
+                    res->c == y->c);
+}
+
+extern "C" int ru3d_conv3d_fwd(const ru3d_tensor* x, const void* w_packed, const float* bias, const ru3d_tensor* res,
+                               const ru3d_tensor* y, int k, int stride, int dtype, int y_dtype, void* stream) {
+    RU3D_REQUIRE(tensor_ok(x) && tensor_ok(y) && w_packed, "conv3d_fwd: bad tensor/weight");
+    RU3D_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "conv3d_fwd: k=%d stride=%d unsupported", k, stride);
+    RU3D_REQUIRE(dtype_ok(dtype) && dtype_ok(y_dtype) && !(dtype == RU3D_F32 && y_dtype == RU3D_BF16),
+                 "conv3d_fwd: bad dtypes %d -> %d", dtype, y_dtype);
+    RU3D_REQUIRE(x->n == y->n && y->d == conv_out(x->d, k, stride) && y->h == conv_out(x->h, k, stride) &&
+                     y->w == conv_out(x->w, k, stride),
+                 "conv3d_fwd: output extents (%d,%d,%d) do not match input (%d,%d,%d) k=%d s=%d", y->d, y->h, y->w,
+                 x->d, x->h, x->w, k, stride);
+    RU3D_REQUIRE(res_ok(res, y), "conv3d_fwd: residual shape mismatch");
+    return run_conv(x, w_packed, bias, res, y, k, stride, 0, 0, 0, dtype, y_dtype, as_stream(stream));
+}
+
+extern "C" int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* res,
+                                 const ru3d_tensor* dx, int k, int stride, int dtype, void* stream) {
+    RU3D_REQUIRE(tensor_ok(dy) && tensor_ok(dx) && w_packed, "conv3d_dgrad: bad tensor/weight");
+    RU3D_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "conv3d_dgrad: k=%d stride=%d unsupported", k, stride);
+    RU3D_REQUIRE(dtype_ok(dtype), "conv3d_dgrad: bad dtype");
+    RU3D_REQUIRE(dx->n == dy->n && dy->d == conv_out(dx->d, k, stride) && dy->h == conv_out(dx->h, k, stride) &&
+                     dy->w == conv_out(dx->w, k, stride),
+                 "conv3d_dgrad: dy extents (%d,%d,%d) do not match dx (%d,%d,%d) k=%d s=%d", dy->d, dy->h, dy->w,
+                 dx->d, dx->h, dx->w, k, stride);
+    RU3D_REQUIRE(res_ok(res, dx), "conv3d_dgrad: residual shape mismatch");
+    // stride 1: gather form with reversed taps; stride 2: transposed (fractionally strided) form
+    if (stride == 1) return run_conv(dy, w_packed, nullptr, res, dx, k, 1, 0, 1, 0, dtype, dtype, as_stream(stream));
+    return run_conv(dy, w_packed, nullptr, res, dx, k, stride, 1, 0, 0, dtype, dtype, as_stream(stream));
+}
+
+static WgradGeom make_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, int k, int stride) {
+    WgradGeom g;
+    g.N = x->n;
+    g.Di = x->d; g.Hi = x->h; g.Wi = x->w; g.Cin = x->c; g.ldx = x->ld;
+    g.Do = dy->d; g.Ho = dy->h; g.Wo = dy->w; g.Cout = dy->c; g.lddy = dy->ld;
+    g.k = k; g.taps = k * k * k; g.stride = stride; g.pad = k / 2;
+    g.s_o = (int64_t)x->c * g.taps;
+    g.s_i = g.taps;
+    g.chunk_len = 0;
+    return g;
+}
+
+static bool wgrad_shapes_ok(const ru3d_tensor* x, const ru3d_tensor* dy, int k, int stride) {
+    return tensor_ok(x) && tensor_ok(dy) && x->n == dy->n && dy->d == conv_out(x->d, k, stride) &&
+           dy->h == conv_out(x->h, k, stride) && dy->w == conv_out(x->w, k, stride);
+}
+
+extern "C" size_t ru3d_conv3d_wgrad_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* dy, int k, int stride,
+                                                    int dtype) {
+    if (!wgrad_shapes_ok(x, dy, k, stride)) return 0;
+    WgradGeom g = make_wgrad(x, dy, k, stride);
+    if (mfma_wgrad_eligible(g, dtype)) return wgrad_mfma_ws_bytes(g);
+    return wgrad_generic_ws_bytes(g);
+}
+
+extern "C" int ru3d_conv3d_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, float* dw, void* ws, size_t ws_bytes,
+                                 int k, int stride, int dtype, void* stream) {
+    RU3D_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "conv3d_wgrad: k=%d stride=%d unsupported", k, stride);
+    RU3D_REQUIRE(wgrad_shapes_ok(x, dy, k, stride), "conv3d_wgrad: x/dy shape mismatch");
+    RU3D_REQUIRE(dw && dtype_ok(dtype), "conv3d_wgrad: bad argument");
+    WgradGeom g = make_wgrad(x, dy, k, stride);
+    if (mfma_wgrad_eligible(g, dtype)) return wgrad_mfma_launch(x->ptr, dy->ptr, dw, ws, ws_bytes, g, as_stream(stream));
+    return wgrad_generic_launch(x->ptr, dy->ptr, dw, ws, ws_bytes, g, dtype, as_stream(stream));
+}
+
+// --------------------------------------------------------------------------- ConvTranspose3d(k3,s2,p1) + far pad
+static bool convt_shapes_ok(const ru3d_tensor* x, const ru3d_tensor* y) {
+    return tensor_ok(x) && tensor_ok(y) && x->n == y->n && y->d == 2 * x->d && y->h == 2 * x->h && y->w == 2 * x->w;
+}
+
+extern "C" int ru3d_convtranspose3d_k3s2p1_fwd(const ru3d_tensor* x, const void* w_packed, const float* bias,
+                                               const ru3d_tensor* y, int dtype, void* stream) {
+    RU3D_REQUIRE(convt_shapes_ok(x, y) && w_packed, "convtranspose3d_fwd: y must have extents 2*x");
+    RU3D_REQUIRE(dtype_ok(dtype), "convtranspose3d_fwd: bad dtype");
+    return run_conv(x, w_packed, bias, nullptr, y, 3, 2, 1, 0, 1, dtype, dtype, as_stream(stream));
+}
+
+extern "C" int ru3d_convtranspose3d_k3s2p1_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* dx,
+                                                 int dtype, void* stream) {
+    RU3D_REQUIRE(convt_shapes_ok(dx, dy) && w_packed, "convtranspose3d_dgrad: dy must have extents 2*dx");
+    RU3D_REQUIRE(dtype_ok(dtype), "convtranspose3d_dgrad: bad dtype");
+    // dx[i] = sum_tap dy[2i - 1 + tap] . W[.,.,tap]: a stride-2 gather conv over dy (far planes of dy are zero)
+    return run_conv(dy, w_packed, nullptr, nullptr, dx, 3, 2, 0, 0, 0, dtype, dtype, as_stream(stream));
+}
+
+static WgradGeom make_convt_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy) {
+    // dW[ci][co][tap] = sum_i x[i][ci] dy[2i-1+tap][co]: wgrad of a stride-2 conv whose gathered
+    // operand is dy and whose dense operand is x.
+    WgradGeom g = make_wgrad(dy, x, 3, 2);
+    g.s_o = (int64_t)dy->c * 27;  // "cout" of this view = x.c = module in_channels (outer dim of W[ci][co][tap])
+    g.s_i = 27;
+    return g;
+}
+
+extern "C" size_t ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* dy,
+                                                                    int dtype) {
+    if (!convt_shapes_ok(x, dy)) return 0;
+    WgradGeom g = make_convt_wgrad(x, dy);
+    if (mfma_wgrad_eligible(g, dtype)) return wgrad_mfma_ws_bytes(g);
+    return wgrad_generic_ws_bytes(g);
+}
+
+extern "C" int ru3d_convtranspose3d_k3s2p1_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, float* dw, void* ws,
+                                                 size_t ws_bytes, int dtype, void* stream) {
+    RU3D_REQUIRE(convt_shapes_ok(x, dy), "convtranspose3d_wgrad: dy must have extents 2*x");
+    RU3D_REQUIRE(dw && dtype_ok(dtype), "convtranspose3d_wgrad: bad argument");
+    WgradGeom g = make_convt_wgrad(x, dy);
+    if (mfma_wgrad_eligible(g, dtype)) return wgrad_mfma_launch(dy->ptr, x->ptr, dw, ws, ws_bytes, g, as_stream(stream));
+    return wgrad_generic_launch(dy->ptr, x->ptr, dw, ws, ws_bytes, g, dtype, as_stream(stream));
+}

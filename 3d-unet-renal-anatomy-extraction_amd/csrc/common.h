@@ -1,0 +1,73 @@
+// Shared device/host helpers for libru3d (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/ru3d.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define RU3D_WAVE 64
+
+int ru3d_fail(int code, const char* fmt, ...);   // sets the thread-local error string, returns code
+int ru3d_check_launch(const char* what);         // hipGetLastError -> status
+
+static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+static inline int64_t nvox(const ru3d_tensor* t) { return (int64_t)t->n * t->d * t->h * t->w; }
+
+static inline int tensor_ok(const ru3d_tensor* t) {
+    return t && t->ptr && t->n > 0 && t->d > 0 && t->h > 0 && t->w > 0 && t->c > 0 && t->ld >= t->c;
+}
+
+#define RU3D_REQUIRE(cond, ...)                        \
+    do {                                               \
+        if (!(cond)) return ru3d_fail(-1, __VA_ARGS__); \
+    } while (0)
+
+// --------------------------------------------------------------------------- device helpers
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16>(bf16 v) { return (float)v; }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+// vector of VEC elements of T, loaded/stored as one access when aligned
+template <typename T, int VEC> struct vec_t {
+    T v[VEC];
+};
+template <typename T, int VEC>
+__device__ __forceinline__ void load_vec(const T* p, float (&out)[VEC]) {
+    typedef __attribute__((ext_vector_type(VEC))) T VT;
+    VT x = *reinterpret_cast<const VT*>(p);
+#pragma unroll
+    for (int i = 0; i < VEC; i++) out[i] = to_f32<T>(x[i]);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_vec(T* p, const float (&in)[VEC]) {
+    typedef __attribute__((ext_vector_type(VEC))) T VT;
+    VT x;
+#pragma unroll
+    for (int i = 0; i < VEC; i++) x[i] = from_f32<T>(in[i]);
+    *reinterpret_cast<VT*>(p) = x;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float lrelu_f(float x, float slope) { return x > 0.f ? x : x * slope; }

@@ -1,0 +1,47 @@
+// Internal geometry structs and launcher prototypes shared by the conv translation units.
+#pragma once
+#include "common.h"
+
+struct ConvGeom {
+    int N;
+    int Di, Hi, Wi, Cin, ldx;    // input tensor (of the data-movement form, not of the nn.Module)
+    int Do, Ho, Wo, Cout, ldy;   // output tensor
+    int CoutPad;                 // generic layout: padded cout of the packed weight
+    int ldr;                     // residual pitch (when res != NULL)
+    int k, stride, pad;
+    int transposed;              // 0 = gather form, 1 = transposed (fractionally strided) form
+    int zero_far;                // write exact zeros on the last plane of each output axis
+    int flip;                    // read weight tap (taps-1-tap): stride-1 dgrad as a gather conv
+};
+
+struct WgradGeom {
+    int N;
+    int Di, Hi, Wi, Cin, ldx;    // "x" operand (gathered with stride/pad)
+    int Do, Ho, Wo, Cout, lddy;  // "dy" operand (dense positions)
+    int k, taps, stride, pad;
+    int64_t s_o, s_i;            // element strides of dw for (cout, cin); tap stride is 1
+    int64_t chunk_len;           // positions per chunk (filled by the launcher)
+};
+
+// conv_generic.hip
+int generic_cot(int cout);
+int generic_cout_pad(int cout);
+int conv_generic_launch(const void* x, const void* w, const float* bias, const void* res, void* y,
+                        const ConvGeom& g, int dtype, int y_dtype, hipStream_t st);
+int pack_generic_launch(const float* src, void* dst, int cin, int cout, int taps, int64_t s_o, int64_t s_i,
+                        int flip, int dtype, hipStream_t st);
+size_t wgrad_generic_ws_bytes(const WgradGeom& g);
+int wgrad_generic_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, WgradGeom g, int dtype,
+                         hipStream_t st);
+
+// conv_mfma.hip (bf16 MFMA implicit GEMM)
+bool mfma_conv_eligible(int cin, int cout, int k, int dtype, int y_dtype);
+size_t mfma_packed_bytes(int cin, int cout, int taps);
+int pack_mfma_launch(const float* src, void* dst, int cin, int cout, int taps, int64_t s_o, int64_t s_i, int flip,
+                     hipStream_t st);
+int conv_mfma_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
+                     hipStream_t st);
+bool mfma_wgrad_eligible(const WgradGeom& g, int dtype);
+size_t wgrad_mfma_ws_bytes(const WgradGeom& g);
+int wgrad_mfma_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, WgradGeom g,
+                      hipStream_t st);

@@ -1,0 +1,308 @@
+// Generic (any channel count, fp32 or bf16 storage, fp32 accumulate) direct convolution kernels.
+//
+// These are the parity-mode kernels (fp32 storage, fixed summation order) and the fallback for
+// shapes the MFMA implicit-GEMM kernels (conv_mfma.hip) do not take (Cin = 1 stem, Cout = 2..4
+// head, F = 30 channel plans).  One kernel covers both data-movement forms the U-Net needs:
+//   gather form      y[o]  = sum_tap x[o*s + tap - p] . W[tap]      (Conv3d fwd; s=1 dgrad; convT dgrad)
+//   transposed form  y[o]  = sum_{tap : (o + p - tap) % s == 0} x[(o + p - tap)/s] . W[tap]
+//                                                                  (ConvTranspose3d fwd; s=2 conv dgrad)
+// Packed weight layout for these kernels: W[tap][cin][cout_pad] in the storage dtype, cout_pad =
+// cout rounded up to the per-thread output-channel tile so the inner loop needs no masking.
+#include "common.h"
+#include "conv.h"
+
+template <typename T, typename TO, int CO_T, int VEC, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void conv_generic_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                           const float* __restrict__ bias,
+                                                           const TO* __restrict__ res, TO* __restrict__ y,
+                                                           ConvGeom g) {
+    const int64_t total = (int64_t)g.N * g.Do * g.Ho * g.Wo;
+    const int64_t vo = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (vo >= total) return;
+    const int co0 = blockIdx.y * CO_T;
+    int ow = (int)(vo % g.Wo);
+    int64_t t = vo / g.Wo;
+    int oh = (int)(t % g.Ho);
+    t /= g.Ho;
+    int od = (int)(t % g.Do);
+    int n = (int)(t / g.Do);
+
+    float acc[CO_T];
+#pragma unroll
+    for (int j = 0; j < CO_T; j++) acc[j] = 0.f;
+
+    const int k = g.k, s = g.stride, p = g.pad;
+    for (int kd = 0; kd < k; kd++) {
+        int id;
+        if (!TRANSPOSED) {
+            id = od * s + kd - p;
+            if (id < 0 || id >= g.Di) continue;
+        } else {
+            int q = od + p - kd;
+            if (q < 0 || (q % s) != 0) continue;
+            id = q / s;
+            if (id >= g.Di) continue;
+        }
+        for (int kh = 0; kh < k; kh++) {
+            int ih;
+            if (!TRANSPOSED) {
+                ih = oh * s + kh - p;
+                if (ih < 0 || ih >= g.Hi) continue;
+            } else {
+                int q = oh + p - kh;
+                if (q < 0 || (q % s) != 0) continue;
+                ih = q / s;
+                if (ih >= g.Hi) continue;
+            }
+            for (int kw = 0; kw < k; kw++) {
+                int iw;
+                if (!TRANSPOSED) {
+                    iw = ow * s + kw - p;
+                    if (iw < 0 || iw >= g.Wi) continue;
+                } else {
+                    int q = ow + p - kw;
+                    if (q < 0 || (q % s) != 0) continue;
+                    iw = q / s;
+                    if (iw >= g.Wi) continue;
+                }
+                const int tap = (kd * k + kh) * k + kw;
+                const T* xp = x + ((((int64_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * g.ldx;
+                const int wtap = g.flip ? (k * k * k - 1 - tap) : tap;
+                const T* wp = w + (int64_t)wtap * g.Cin * g.CoutPad + co0;
+                for (int ci = 0; ci < g.Cin; ci += VEC) {
+                    float xv[VEC];
+                    load_vec<T, VEC>(xp + ci, xv);
+#pragma unroll
+                    for (int u = 0; u < VEC; u++) {
+                        const T* wr = wp + (int64_t)(ci + u) * g.CoutPad;
+#pragma unroll
+                        for (int j = 0; j < CO_T; j++) acc[j] = fmaf(xv[u], to_f32<T>(wr[j]), acc[j]);
+                    }
+                }
+            }
+        }
+    }
+    const bool far = g.zero_far && (od == g.Do - 1 || oh == g.Ho - 1 || ow == g.Wo - 1);
+#pragma unroll
+    for (int j = 0; j < CO_T; j++) {
+        const int co = co0 + j;
+        if (co < g.Cout) {
+            float v = acc[j];
+            if (bias) v += bias[co];
+            if (far) v = 0.f;
+            if (res) v += to_f32<TO>(res[vo * g.ldr + co]);
+            y[vo * g.ldy + co] = from_f32<TO>(v);
+        }
+    }
+}
+
+int generic_cot(int cout) { return cout <= 4 ? 4 : (cout % 16 == 0 ? 16 : 8); }
+int generic_cout_pad(int cout) {
+    int t = generic_cot(cout);
+    return (cout + t - 1) / t * t;
+}
+
+template <typename T, typename TO, int CO_T, int VEC>
+static int launch_generic2(const void* x, const void* w, const float* bias, const void* res, void* y,
+                           const ConvGeom& g, hipStream_t st) {
+    const int64_t total = (int64_t)g.N * g.Do * g.Ho * g.Wo;
+    dim3 grid((unsigned)((total + 255) / 256), (unsigned)(g.CoutPad / CO_T));
+    if (g.transposed)
+        hipLaunchKernelGGL((conv_generic_kernel<T, TO, CO_T, VEC, true>), grid, dim3(256), 0, st, (const T*)x,
+                           (const T*)w, bias, (const TO*)res, (TO*)y, g);
+    else
+        hipLaunchKernelGGL((conv_generic_kernel<T, TO, CO_T, VEC, false>), grid, dim3(256), 0, st, (const T*)x,
+                           (const T*)w, bias, (const TO*)res, (TO*)y, g);
+    return ru3d_check_launch("conv_generic");
+}
+
+template <typename T, typename TO>
+static int launch_generic1(const void* x, const void* w, const float* bias, const void* res, void* y,
+                           const ConvGeom& g, hipStream_t st) {
+    const bool v4 = (g.Cin % 4 == 0) && (g.ldx % 4 == 0) && (((uintptr_t)x) % (4 * sizeof(T)) == 0);
+    const int cot = generic_cot(g.Cout);
+#define GO(CO, V) return launch_generic2<T, TO, CO, V>(x, w, bias, res, y, g, st)
+    if (cot == 4) { if (v4) GO(4, 4); else GO(4, 1); }
+    if (cot == 8) { if (v4) GO(8, 4); else GO(8, 1); }
+    if (v4) GO(16, 4); else GO(16, 1);
+#undef GO
+}
+
+int conv_generic_launch(const void* x, const void* w, const float* bias, const void* res, void* y,
+                        const ConvGeom& g, int dtype, int y_dtype, hipStream_t st) {
+    if (dtype == RU3D_F32 && y_dtype == RU3D_F32) return launch_generic1<float, float>(x, w, bias, res, y, g, st);
+    if (dtype == RU3D_BF16 && y_dtype == RU3D_BF16) return launch_generic1<bf16, bf16>(x, w, bias, res, y, g, st);
+    if (dtype == RU3D_BF16 && y_dtype == RU3D_F32) return launch_generic1<bf16, float>(x, w, bias, res, y, g, st);
+    return ru3d_fail(-1, "conv_generic: unsupported dtype pair (%d -> %d)", dtype, y_dtype);
+}
+
+// --------------------------------------------------------------------------- weight packing
+// dst[tap'][ci'][co'] (cout padded) <- src[co'*s_o + ci'*s_i + tap], tap flipped for the s=1 dgrad.
+template <typename T>
+__global__ void pack_generic_kernel(const float* __restrict__ src, T* __restrict__ dst, int cin, int cout,
+                                    int cout_pad, int taps, int64_t s_o, int64_t s_i, int flip) {
+    const int64_t total = (int64_t)taps * cin * cout_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int co = (int)(i % cout_pad);
+        int64_t t = i / cout_pad;
+        int ci = (int)(t % cin);
+        int tap = (int)(t / cin);
+        float v = 0.f;
+        if (co < cout) {
+            int st = flip ? (taps - 1 - tap) : tap;
+            v = src[co * s_o + ci * s_i + st];
+        }
+        dst[i] = from_f32<T>(v);
+    }
+}
+
+int pack_generic_launch(const float* src, void* dst, int cin, int cout, int taps, int64_t s_o, int64_t s_i,
+                        int flip, int dtype, hipStream_t st) {
+    const int cp = generic_cout_pad(cout);
+    const int64_t total = (int64_t)taps * cin * cp;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == RU3D_F32)
+        hipLaunchKernelGGL(pack_generic_kernel<float>, dim3(blocks), dim3(256), 0, st, src, (float*)dst, cin, cout, cp,
+                           taps, s_o, s_i, flip);
+    else
+        hipLaunchKernelGGL(pack_generic_kernel<bf16>, dim3(blocks), dim3(256), 0, st, src, (bf16*)dst, cin, cout, cp,
+                           taps, s_o, s_i, flip);
+    return ru3d_check_launch("pack_generic");
+}
+
+// --------------------------------------------------------------------------- generic wgrad
+// dW[tap][ci][co] = sum_pos x[s*pos + tap - p][ci] * dy[pos][co], pos over N*Do*Ho*Wo.
+// grid = (chunks, taps, ci_tiles*co_tiles); block = 64x64 (ci x co) tile, 16 positions per LDS stage,
+// each thread a 4x4 register tile.  Partials go to the workspace and are summed in a fixed order by
+// wgrad_reduce_kernel (deterministic: no atomics).
+#define WG_PB 16
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_generic_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                            float* __restrict__ part, WgradGeom g) {
+    __shared__ float xs[WG_PB][64 + 4];
+    __shared__ float ds[WG_PB][64 + 4];
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x, tap = blockIdx.y;
+    const int co_tiles = (g.Cout + 63) / 64;
+    const int ci0 = (blockIdx.z / co_tiles) * 64, co0 = (blockIdx.z % co_tiles) * 64;
+    const int kw = tap % g.k, kh = (tap / g.k) % g.k, kd = tap / (g.k * g.k);
+    const int ty = tid / 16, tx = tid % 16;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = 0.f;
+
+    const int64_t P = (int64_t)g.N * g.Do * g.Ho * g.Wo;
+    const int64_t p_begin = (int64_t)chunk * g.chunk_len;
+    int64_t p_end = p_begin + g.chunk_len;
+    if (p_end > P) p_end = P;
+
+    for (int64_t p0 = p_begin; p0 < p_end; p0 += WG_PB) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int e = tid + r * 256;
+            const int pl = e / 64, c = e % 64;
+            const int64_t pos = p0 + pl;
+            float xv = 0.f, dv = 0.f;
+            if (pos < p_end) {
+                int ow = (int)(pos % g.Wo);
+                int64_t t = pos / g.Wo;
+                int oh = (int)(t % g.Ho);
+                t /= g.Ho;
+                int od = (int)(t % g.Do);
+                int n = (int)(t / g.Do);
+                if (co0 + c < g.Cout) dv = to_f32<T>(dy[pos * g.lddy + co0 + c]);
+                const int id = od * g.stride + kd - g.pad, ih = oh * g.stride + kh - g.pad,
+                          iw = ow * g.stride + kw - g.pad;
+                if (ci0 + c < g.Cin && id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                    xv = to_f32<T>(x[((((int64_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * g.ldx + ci0 + c]);
+            }
+            xs[pl][c] = xv;
+            ds[pl][c] = dv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pl = 0; pl < WG_PB; pl++) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) a[i] = xs[pl][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[j] = ds[pl][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    float* pp = part + ((int64_t)chunk * g.taps + tap) * g.Cin * g.Cout;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int ci = ci0 + ty * 4 + i;
+        if (ci >= g.Cin) continue;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int co = co0 + tx * 4 + j;
+            if (co < g.Cout) pp[(int64_t)ci * g.Cout + co] = acc[i][j];
+        }
+    }
+}
+
+// dw[co*s_o + ci*s_i + tap] = sum_chunk part[chunk][tap][ci][co]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int chunks, int taps,
+                                    int cin, int cout, int64_t s_o, int64_t s_i) {
+    const int64_t total = (int64_t)taps * cin * cout;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < chunks; c++) s += part[(int64_t)c * total + i];
+        int co = (int)(i % cout);
+        int64_t t = i / cout;
+        int ci = (int)(t % cin);
+        int tap = (int)(t / cin);
+        dw[co * s_o + ci * s_i + tap] = s;
+    }
+}
+
+int wgrad_generic_chunks(const WgradGeom& g) {
+    const int64_t P = (int64_t)g.N * g.Do * g.Ho * g.Wo;
+    const int tiles = ((g.Cin + 63) / 64) * ((g.Cout + 63) / 64);
+    int64_t want = 2048 / ((int64_t)g.taps * tiles);
+    if (want < 1) want = 1;
+    int64_t maxc = (P + WG_PB * 16 - 1) / (WG_PB * 16);
+    if (want > maxc) want = maxc;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+size_t wgrad_generic_ws_bytes(const WgradGeom& g) {
+    return (size_t)wgrad_generic_chunks(g) * g.taps * g.Cin * g.Cout * sizeof(float);
+}
+
+int wgrad_generic_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, WgradGeom g, int dtype,
+                         hipStream_t st) {
+    const int chunks = wgrad_generic_chunks(g);
+    const size_t need = wgrad_generic_ws_bytes(g);
+    if (!ws || ws_bytes < need) return ru3d_fail(-1, "wgrad: workspace too small (%zu < %zu)", ws_bytes, need);
+    const int64_t P = (int64_t)g.N * g.Do * g.Ho * g.Wo;
+    int64_t len = (P + chunks - 1) / chunks;
+    len = (len + WG_PB - 1) / WG_PB * WG_PB;
+    g.chunk_len = len;
+    const int tiles = ((g.Cin + 63) / 64) * ((g.Cout + 63) / 64);
+    dim3 grid(chunks, g.taps, tiles);
+    if (dtype == RU3D_F32)
+        hipLaunchKernelGGL(wgrad_generic_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy,
+                           (float*)ws, g);
+    else
+        hipLaunchKernelGGL(wgrad_generic_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy,
+                           (float*)ws, g);
+    int rc = ru3d_check_launch("wgrad_generic");
+    if (rc) return rc;
+    const int64_t total = (int64_t)g.taps * g.Cin * g.Cout;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, chunks, g.taps,
+                       g.Cin, g.Cout, g.s_o, g.s_i);
+    return ru3d_check_launch("wgrad_reduce");
+}

@@ -1,0 +1,626 @@
+// InstanceNorm3d + LeakyReLU (+ residual, + folded Dropout3d) forward/backward, per-channel sums,
+// channel-slice copy, add, layout repack.  All HBM-bound: 16-byte accesses, channels on the lanes,
+// per-(n,c) parameters held in registers across a voxel loop, no integer division per element.
+//
+// Work decomposition shared by every kernel here ("channel loop"): a tensor is [N][V][C] with pitch
+// ld.  Channels are cut into groups of VEC elements (one 16-byte access for bf16x8 / f32x4); a block
+// of 256 threads owns Gb <= 256 channel groups x vpb = 256/Gb voxel lanes and walks a span of voxels.
+// grid = (chunks, N, group blocks).
+#include "common.h"
+#include <initializer_list>
+
+struct ChanLoop {
+    int V;      // voxels per sample
+    int G;      // channel groups (C / VEC)
+    int Gb;     // groups per block
+    int vpb;    // voxel lanes per block
+    int span;   // voxels per block
+    int chunks; // blocks along the voxel axis
+};
+
+static ChanLoop make_chanloop(int64_t V, int C, int vec, int max_iters) {
+    ChanLoop cl;
+    cl.V = (int)V;
+    cl.G = C / vec;
+    cl.Gb = cl.G < 256 ? cl.G : 256;
+    cl.vpb = 256 / cl.Gb;
+    int64_t span = (int64_t)cl.vpb * max_iters;
+    int64_t chunks = (V + span - 1) / span;
+    if (chunks > 4096) {
+        chunks = 4096;
+        span = (V + chunks - 1) / chunks;
+        span = (span + cl.vpb - 1) / cl.vpb * cl.vpb;
+        chunks = (V + span - 1) / span;
+    }
+    cl.span = (int)span;
+    cl.chunks = (int)chunks;
+    return cl;
+}
+
+template <typename T>
+static int pick_vec(int c, std::initializer_list<const ru3d_tensor*> ts) {
+    int vec = 16 / (int)sizeof(T);
+    for (; vec > 1; vec >>= 1) {
+        bool ok = (c % vec) == 0;
+        for (const ru3d_tensor* t : ts) {
+            if (!t) continue;
+            ok = ok && (t->ld % vec == 0) && (((uintptr_t)t->ptr) % (vec * sizeof(T)) == 0);
+        }
+        if (ok) break;
+    }
+    return vec;
+}
+
+// --------------------------------------------------------------------------- two-sum reduction
+// MODE 0: (sum y, sum y^2)                                 InstanceNorm statistics
+// MODE 1: (sum gpre, sum gpre*xhat)                        InstanceNorm backward
+// MODE 2: (sum t, 0)                                       bias gradient
+// Partials: part[((n*chunks + chunk)*C + c)*2 + {0,1}] as double.
+template <typename T, int VEC, int MODE>
+__global__ __launch_bounds__(256) void reduce2_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b,
+                                                      int ldb, const T* __restrict__ c3, int ldc,
+                                                      const float* __restrict__ mean, const float* __restrict__ scale,
+                                                      float slope, double* __restrict__ part, ChanLoop cl, int C) {
+    __shared__ double sh[2][256][VEC > 4 ? 4 : VEC];  // reduced in two halves when VEC == 8
+    const int tid = threadIdx.x;
+    const int cgl = tid % cl.Gb, vl = tid / cl.Gb;
+    const int cg = blockIdx.z * cl.Gb + cgl;
+    const int n = blockIdx.y;
+    const bool active = (vl < cl.vpb) && (cg < cl.G);
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) s1[i] = s2[i] = 0.f;
+    if (active) {
+        float mu[VEC], sc[VEC];
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < VEC; i++) {
+                mu[i] = mean[n * C + cg * VEC + i];
+                sc[i] = scale[n * C + cg * VEC + i];
+            }
+        }
+        const int v0 = blockIdx.x * cl.span;
+        int v1 = v0 + cl.span;
+        if (v1 > cl.V) v1 = cl.V;
+        for (int v = v0 + vl; v < v1; v += cl.vpb) {
+            const int64_t row = (int64_t)n * cl.V + v;
+            float av[VEC];
+            load_vec<T, VEC>(a + row * lda + cg * VEC, av);
+            if (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < VEC; i++) {
+                    s1[i] += av[i];
+                    s2[i] = fmaf(av[i], av[i], s2[i]);
+                }
+            } else if (MODE == 1) {
+                float ov[VEC], yv[VEC];
+                load_vec<T, VEC>(b + row * ldb + cg * VEC, ov);
+                load_vec<T, VEC>(c3 + row * ldc + cg * VEC, yv);
+#pragma unroll
+                for (int i = 0; i < VEC; i++) {
+                    const float gp = ov[i] > 0.f ? av[i] : av[i] * slope;
+                    const float xh = (yv[i] - mu[i]) * sc[i];
+                    s1[i] += gp;
+                    s2[i] = fmaf(gp, xh, s2[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; i++) s1[i] += av[i];
+            }
+        }
+    }
+    // cross voxel-lane reduction in LDS (double), fixed order -> deterministic
+    constexpr int HV = VEC > 4 ? 4 : VEC;
+#pragma unroll
+    for (int half = 0; half < VEC / HV; half++) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < HV; i++) {
+            sh[0][tid][i] = active ? (double)s1[half * HV + i] : 0.0;
+            sh[1][tid][i] = active ? (double)s2[half * HV + i] : 0.0;
+        }
+        __syncthreads();
+        if (vl == 0 && cg < cl.G) {
+#pragma unroll
+            for (int i = 0; i < HV; i++) {
+                double t1 = 0.0, t2 = 0.0;
+                for (int l = 0; l < cl.vpb; l++) {
+                    t1 += sh[0][l * cl.Gb + cgl][i];
+                    t2 += sh[1][l * cl.Gb + cgl][i];
+                }
+                const int c = cg * VEC + half * HV + i;
+                double* pp = part + (((int64_t)n * cl.chunks + blockIdx.x) * C + c) * 2;
+                pp[0] = t1;
+                pp[1] = t2;
+            }
+        }
+    }
+}
+
+// stats finalize: mean, scale = s / sqrt(s^2 var + eps)
+__global__ void stats_finalize_kernel(const double* __restrict__ part, int chunks, int C, int NC, double invV,
+                                      const float* __restrict__ drop, float eps, float* __restrict__ mean,
+                                      float* __restrict__ scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC) return;
+    const int n = i / C, c = i % C;
+    double t1 = 0.0, t2 = 0.0;
+    for (int k = 0; k < chunks; k++) {
+        const double* pp = part + (((int64_t)n * chunks + k) * C + c) * 2;
+        t1 += pp[0];
+        t2 += pp[1];
+    }
+    const double m = t1 * invV;
+    double var = t2 * invV - m * m;
+    if (var < 0.0) var = 0.0;
+    const double s = drop ? (double)drop[i] : 1.0;
+    mean[i] = (float)m;
+    scale[i] = (float)(s / sqrt(s * s * var + (double)eps));
+}
+
+// backward finalize: m1 = mean(gpre), m2 = mean(gpre * xhat), stored right after the partials
+__global__ void bwd_finalize_kernel(const double* __restrict__ part, int chunks, int C, int NC, double invV,
+                                    float* __restrict__ m12) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NC) return;
+    const int n = i / C, c = i % C;
+    double t1 = 0.0, t2 = 0.0;
+    for (int k = 0; k < chunks; k++) {
+        const double* pp = part + (((int64_t)n * chunks + k) * C + c) * 2;
+        t1 += pp[0];
+        t2 += pp[1];
+    }
+    m12[2 * i] = (float)(t1 * invV);
+    m12[2 * i + 1] = (float)(t2 * invV);
+}
+
+__global__ void chansum_finalize_kernel(const double* __restrict__ part, int chunks, int C, int N,
+                                        float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double t = 0.0;
+    for (int n = 0; n < N; n++)
+        for (int k = 0; k < chunks; k++) t += part[(((int64_t)n * chunks + k) * C + c) * 2];
+    out[c] = (float)t;
+}
+
+// --------------------------------------------------------------------------- apply kernels
+// out = lrelu((y - mean) * scale (+ res))
+template <typename T, int VEC, bool HAS_RES>
+__global__ __launch_bounds__(256) void in_lrelu_fwd_kernel(const T* __restrict__ y, int ldy,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ scale, const T* __restrict__ res,
+                                                           int ldr, T* __restrict__ out, int ldo, float slope,
+                                                           ChanLoop cl, int C) {
+    const int tid = threadIdx.x;
+    const int cgl = tid % cl.Gb, vl = tid / cl.Gb;
+    const int cg = blockIdx.z * cl.Gb + cgl;
+    const int n = blockIdx.y;
+    if (vl >= cl.vpb || cg >= cl.G) return;
+    float mu[VEC], sc[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+        mu[i] = mean[n * C + cg * VEC + i];
+        sc[i] = scale[n * C + cg * VEC + i];
+    }
+    const int v0 = blockIdx.x * cl.span;
+    int v1 = v0 + cl.span;
+    if (v1 > cl.V) v1 = cl.V;
+    for (int v = v0 + vl; v < v1; v += cl.vpb) {
+        const int64_t row = (int64_t)n * cl.V + v;
+        float yv[VEC], rv[VEC], ov[VEC];
+        load_vec<T, VEC>(y + row * ldy + cg * VEC, yv);
+        if (HAS_RES) load_vec<T, VEC>(res + row * ldr + cg * VEC, rv);
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+            float t = (yv[i] - mu[i]) * sc[i];
+            if (HAS_RES) t += rv[i];
+            ov[i] = lrelu_f(t, slope);
+        }
+        store_vec<T, VEC>(out + row * ldo + cg * VEC, ov);
+    }
+}
+
+// dy = scale * (gpre - m1 - xhat * m2), gpre = gout * lrelu'(out); optional gpre output; far planes zeroed
+template <typename T, int VEC, bool HAS_GPRE>
+__global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(const T* __restrict__ gout, int ldg,
+                                                           const T* __restrict__ out, int ldo,
+                                                           const T* __restrict__ y, int ldy,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ m12, T* __restrict__ dy, int lddy,
+                                                           T* __restrict__ gpre, int ldgp, float slope, int zero_far,
+                                                           int D, int H, int W, ChanLoop cl, int C) {
+    const int tid = threadIdx.x;
+    const int cgl = tid % cl.Gb, vl = tid / cl.Gb;
+    const int cg = blockIdx.z * cl.Gb + cgl;
+    const int n = blockIdx.y;
+    if (vl >= cl.vpb || cg >= cl.G) return;
+    float mu[VEC], sc[VEC], m1[VEC], m2[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+        const int idx = n * C + cg * VEC + i;
+        mu[i] = mean[idx];
+        sc[i] = scale[idx];
+        m1[i] = m12[2 * idx];
+        m2[i] = m12[2 * idx + 1];
+    }
+    const int v0 = blockIdx.x * cl.span;
+    int v1 = v0 + cl.span;
+    if (v1 > cl.V) v1 = cl.V;
+    for (int v = v0 + vl; v < v1; v += cl.vpb) {
+        const int64_t row = (int64_t)n * cl.V + v;
+        float gv[VEC], ov[VEC], yv[VEC], dv[VEC], pv[VEC];
+        load_vec<T, VEC>(gout + row * ldg + cg * VEC, gv);
+        load_vec<T, VEC>(out + row * ldo + cg * VEC, ov);
+        load_vec<T, VEC>(y + row * ldy + cg * VEC, yv);
+        bool far = false;
+        if (zero_far) {
+            const int w = v % W, h = (v / W) % H, d = v / (W * H);
+            far = (w == W - 1) || (h == H - 1) || (d == D - 1);
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+            const float gp = ov[i] > 0.f ? gv[i] : gv[i] * slope;
+            const float xh = (yv[i] - mu[i]) * sc[i];
+            pv[i] = gp;
+            dv[i] = far ? 0.f : sc[i] * (gp - m1[i] - xh * m2[i]);
+        }
+        store_vec<T, VEC>(dy + row * lddy + cg * VEC, dv);
+        if (HAS_GPRE) store_vec<T, VEC>(gpre + row * ldgp + cg * VEC, pv);
+    }
+}
+
+// dst = a (+ b)
+template <typename T, int VEC, bool ADD>
+__global__ __launch_bounds__(256) void copy_add_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b,
+                                                       int ldb, T* __restrict__ dst, int ldd, ChanLoop cl) {
+    const int tid = threadIdx.x;
+    const int cgl = tid % cl.Gb, vl = tid / cl.Gb;
+    const int cg = blockIdx.z * cl.Gb + cgl;
+    const int n = blockIdx.y;
+    if (vl >= cl.vpb || cg >= cl.G) return;
+    const int v0 = blockIdx.x * cl.span;
+    int v1 = v0 + cl.span;
+    if (v1 > cl.V) v1 = cl.V;
+    for (int v = v0 + vl; v < v1; v += cl.vpb) {
+        const int64_t row = (int64_t)n * cl.V + v;
+        float av[VEC], bv[VEC];
+        load_vec<T, VEC>(a + row * lda + cg * VEC, av);
+        if (ADD) {
+            load_vec<T, VEC>(b + row * ldb + cg * VEC, bv);
+#pragma unroll
+            for (int i = 0; i < VEC; i++) av[i] += bv[i];
+        }
+        store_vec<T, VEC>(dst + row * ldd + cg * VEC, av);
+    }
+}
+
+// --------------------------------------------------------------------------- dispatch helpers
+#define DISPATCH_VEC(T, vec, CALL)                 \
+    switch (vec) {                                 \
+        case 8: if constexpr (sizeof(T) == 2) { CALL(T, 8); } break; \
+        case 4: CALL(T, 4); break;                 \
+        case 2: CALL(T, 2); break;                 \
+        default: CALL(T, 1); break;                \
+    }
+
+static bool same_shape(const ru3d_tensor* a, const ru3d_tensor* b) {
+    return a->n == b->n && a->d == b->d && a->h == b->h && a->w == b->w && a->c == b->c;
+}
+
+static size_t reduce_ws_bytes(const ru3d_tensor* t) {
+    // upper bound over the VEC choices: chunks is largest when vpb is smallest
+    int64_t V = (int64_t)t->d * t->h * t->w;
+    int64_t chunks = V < 4096 ? V : 4096;
+    if (chunks < 1) chunks = 1;
+    return (size_t)t->n * chunks * t->c * 2 * sizeof(double) + (size_t)t->n * t->c * 2 * sizeof(float) + 256;
+}
+
+extern "C" size_t ru3d_reduce_workspace_bytes(const ru3d_tensor* t) { return t ? reduce_ws_bytes(t) : 0; }
+
+template <typename T>
+static int stats_impl(const ru3d_tensor* y, const float* drop, float* mean, float* scale, void* ws, float eps,
+                      hipStream_t st) {
+    const int64_t V = (int64_t)y->d * y->h * y->w;
+    const int vec = pick_vec<T>(y->c, {y});
+    ChanLoop cl = make_chanloop(V, y->c, vec, 64);
+    dim3 grid(cl.chunks, y->n, (cl.G + cl.Gb - 1) / cl.Gb);
+    double* part = (double*)ws;
+#define CALL(TT, VV)                                                                                              \
+    hipLaunchKernelGGL((reduce2_kernel<TT, VV, 0>), grid, dim3(256), 0, st, (const TT*)y->ptr, y->ld, (const TT*)0, \
+                       0, (const TT*)0, 0, (const float*)0, (const float*)0, 0.f, part, cl, y->c)
+    DISPATCH_VEC(T, vec, CALL)
+#undef CALL
+    int rc = ru3d_check_launch("instnorm_stats");
+    if (rc) return rc;
+    const int NC = y->n * y->c;
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((NC + 255) / 256), dim3(256), 0, st, (const double*)part, cl.chunks,
+                       y->c, NC, 1.0 / (double)V, drop, eps, mean, scale);
+    return ru3d_check_launch("instnorm_stats_finalize");
+}
+
+extern "C" int ru3d_instnorm_stats(const ru3d_tensor* y, const float* drop_scale, float* mean, float* scale, void* ws,
+                                   size_t ws_bytes, float eps, int dtype, void* stream) {
+    RU3D_REQUIRE(tensor_ok(y), "instnorm_stats: bad tensor");
+    RU3D_REQUIRE(mean && scale && ws, "instnorm_stats: null output/workspace");
+    RU3D_REQUIRE(ws_bytes >= reduce_ws_bytes(y), "instnorm_stats: workspace too small (%zu < %zu)", ws_bytes,
+                 reduce_ws_bytes(y));
+    RU3D_REQUIRE((int64_t)y->d * y->h * y->w < (1ll << 31), "instnorm_stats: sample too large");
+    if (dtype == RU3D_F32) return stats_impl<float>(y, drop_scale, mean, scale, ws, eps, as_stream(stream));
+    if (dtype == RU3D_BF16) return stats_impl<bf16>(y, drop_scale, mean, scale, ws, eps, as_stream(stream));
+    return ru3d_fail(-1, "instnorm_stats: bad dtype %d", dtype);
+}
+
+template <typename T>
+static int in_fwd_impl(const ru3d_tensor* y, const float* mean, const float* scale, const ru3d_tensor* res,
+                       const ru3d_tensor* out, float slope, hipStream_t st) {
+    const int64_t V = (int64_t)y->d * y->h * y->w;
+    const int vec = pick_vec<T>(y->c, {y, res, out});
+    ChanLoop cl = make_chanloop(V, y->c, vec, 16);
+    dim3 grid(cl.chunks, y->n, (cl.G + cl.Gb - 1) / cl.Gb);
+#define CALL(TT, VV)                                                                                               \
+    if (res)                                                                                                       \
+        hipLaunchKernelGGL((in_lrelu_fwd_kernel<TT, VV, true>), grid, dim3(256), 0, st, (const TT*)y->ptr, y->ld,   \
+                           mean, scale, (const TT*)res->ptr, res->ld, (TT*)out->ptr, out->ld, slope, cl, y->c);    \
+    else                                                                                                           \
+        hipLaunchKernelGGL((in_lrelu_fwd_kernel<TT, VV, false>), grid, dim3(256), 0, st, (const TT*)y->ptr, y->ld,  \
+                           mean, scale, (const TT*)0, 0, (TT*)out->ptr, out->ld, slope, cl, y->c)
+    DISPATCH_VEC(T, vec, CALL)
+#undef CALL
+    return ru3d_check_launch("in_lrelu_fwd");
+}
+
+extern "C" int ru3d_in_lrelu_fwd(const ru3d_tensor* y, const float* mean, const float* scale, const ru3d_tensor* res,
+                                 const ru3d_tensor* out, float slope, int dtype, void* stream) {
+    RU3D_REQUIRE(tensor_ok(y) && tensor_ok(out) && same_shape(y, out), "in_lrelu_fwd: bad y/out");
+    RU3D_REQUIRE(!res || (tensor_ok(res) && same_shape(y, res)), "in_lrelu_fwd: bad residual");
+    RU3D_REQUIRE(mean && scale, "in_lrelu_fwd: null stats");
+    RU3D_REQUIRE((int64_t)y->d * y->h * y->w < (1ll << 31), "in_lrelu_fwd: sample too large");
+    if (dtype == RU3D_F32) return in_fwd_impl<float>(y, mean, scale, res, out, slope, as_stream(stream));
+    if (dtype == RU3D_BF16) return in_fwd_impl<bf16>(y, mean, scale, res, out, slope, as_stream(stream));
+    return ru3d_fail(-1, "in_lrelu_fwd: bad dtype %d", dtype);
+}
+
+template <typename T>
+static int in_bwd_impl(const ru3d_tensor* gout, const ru3d_tensor* out, const ru3d_tensor* y, const float* mean,
+                       const float* scale, const ru3d_tensor* dy, const ru3d_tensor* gpre, void* ws, float slope,
+                       int zero_far, hipStream_t st) {
+    const int64_t V = (int64_t)y->d * y->h * y->w;
+    const int vec = pick_vec<T>(y->c, {gout, out, y, dy, gpre});
+    ChanLoop cl = make_chanloop(V, y->c, vec, 64);
+    dim3 grid(cl.chunks, y->n, (cl.G + cl.Gb - 1) / cl.Gb);
+    double* part = (double*)ws;
+    const int NC = y->n * y->c;
+    float* m12 = (float*)((char*)ws + (size_t)y->n * cl.chunks * y->c * 2 * sizeof(double));
+#define CALL(TT, VV)                                                                                                  \
+    hipLaunchKernelGGL((reduce2_kernel<TT, VV, 1>), grid, dim3(256), 0, st, (const TT*)gout->ptr, gout->ld,           \
+                       (const TT*)out->ptr, out->ld, (const TT*)y->ptr, y->ld, mean, scale, slope, part, cl, y->c)
+    DISPATCH_VEC(T, vec, CALL)
+#undef CALL
+    int rc = ru3d_check_launch("in_lrelu_bwd_reduce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bwd_finalize_kernel, dim3((NC + 255) / 256), dim3(256), 0, st, (const double*)part, cl.chunks,
+                       y->c, NC, 1.0 / (double)V, m12);
+    rc = ru3d_check_launch("in_lrelu_bwd_finalize");
+    if (rc) return rc;
+    ChanLoop ca = make_chanloop(V, y->c, vec, 16);
+    dim3 grida(ca.chunks, y->n, (ca.G + ca.Gb - 1) / ca.Gb);
+#define CALL(TT, VV)                                                                                                  \
+    if (gpre)                                                                                                         \
+        hipLaunchKernelGGL((in_lrelu_bwd_kernel<TT, VV, true>), grida, dim3(256), 0, st, (const TT*)gout->ptr,        \
+                           gout->ld, (const TT*)out->ptr, out->ld, (const TT*)y->ptr, y->ld, mean, scale,            \
+                           (const float*)m12, (TT*)dy->ptr, dy->ld, (TT*)gpre->ptr, gpre->ld, slope, zero_far, y->d,  \
+                           y->h, y->w, ca, y->c);                                                                     \
+    else                                                                                                              \
+        hipLaunchKernelGGL((in_lrelu_bwd_kernel<TT, VV, false>), grida, dim3(256), 0, st, (const TT*)gout->ptr,       \
+                           gout->ld, (const TT*)out->ptr, out->ld, (const TT*)y->ptr, y->ld, mean, scale,            \
+                           (const float*)m12, (TT*)dy->ptr, dy->ld, (TT*)0, 0, slope, zero_far, y->d, y->h, y->w, ca, \
+                           y->c)
+    DISPATCH_VEC(T, vec, CALL)
+#undef CALL
+    return ru3d_check_launch("in_lrelu_bwd_apply");
+}
+
+extern "C" int ru3d_in_lrelu_bwd(const ru3d_tensor* gout, const ru3d_tensor* out, const ru3d_tensor* y,
+                                 const float* mean, const float* scale, const ru3d_tensor* dy,
+                                 const ru3d_tensor* gpre, void* ws, size_t ws_bytes, float slope, int zero_far,
+                                 int dtype, void* stream) {
+    RU3D_REQUIRE(tensor_ok(gout) && tensor_ok(out) && tensor_ok(y) && tensor_ok(dy), "in_lrelu_bwd: bad tensor");
+    RU3D_REQUIRE(same_shape(y, gout) && same_shape(y, out) && same_shape(y, dy), "in_lrelu_bwd: shape mismatch");
+    RU3D_REQUIRE(!gpre || (tensor_ok(gpre) && same_shape(y, gpre)), "in_lrelu_bwd: bad gpre");
+    RU3D_REQUIRE(mean && scale && ws, "in_lrelu_bwd: null stats/workspace");
+    RU3D_REQUIRE(ws_bytes >= reduce_ws_bytes(y), "in_lrelu_bwd: workspace too small (%zu < %zu)", ws_bytes,
+                 reduce_ws_bytes(y));
+    RU3D_REQUIRE((int64_t)y->d * y->h * y->w < (1ll << 31), "in_lrelu_bwd: sample too large");
+    if (dtype == RU3D_F32)
+        return in_bwd_impl<float>(gout, out, y, mean, scale, dy, gpre, ws, slope, zero_far, as_stream(stream));
+    if (dtype == RU3D_BF16)
+        return in_bwd_impl<bf16>(gout, out, y, mean, scale, dy, gpre, ws, slope, zero_far, as_stream(stream));
+    return ru3d_fail(-1, "in_lrelu_bwd: bad dtype %d", dtype);
+}
+
+template <typename T>
+static int chansum_impl(const ru3d_tensor* t, float* out, void* ws, hipStream_t st) {
+    const int64_t V = (int64_t)t->d * t->h * t->w;
+    const int vec = pick_vec<T>(t->c, {t});
+    ChanLoop cl = make_chanloop(V, t->c, vec, 64);
+    dim3 grid(cl.chunks, t->n, (cl.G + cl.Gb - 1) / cl.Gb);
+    double* part = (double*)ws;
+#define CALL(TT, VV)                                                                                              \
+    hipLaunchKernelGGL((reduce2_kernel<TT, VV, 2>), grid, dim3(256), 0, st, (const TT*)t->ptr, t->ld, (const TT*)0, \
+                       0, (const TT*)0, 0, (const float*)0, (const float*)0, 0.f, part, cl, t->c)
+    DISPATCH_VEC(T, vec, CALL)
+#undef CALL
+    int rc = ru3d_check_launch("channel_sum");
+    if (rc) return rc;
+    hipLaunchKernelGGL(chansum_finalize_kernel, dim3((t->c + 255) / 256), dim3(256), 0, st, (const double*)part,
+                       cl.chunks, t->c, t->n, out);
+    return ru3d_check_launch("channel_sum_finalize");
+}
+
+extern "C" int ru3d_channel_sum(const ru3d_tensor* t, float* out, void* ws, size_t ws_bytes, int dtype,
+                                void* stream) {
+    RU3D_REQUIRE(tensor_ok(t) && out && ws, "channel_sum: bad argument");
+    RU3D_REQUIRE(ws_bytes >= reduce_ws_bytes(t), "channel_sum: workspace too small");
+    RU3D_REQUIRE((int64_t)t->d * t->h * t->w < (1ll << 31), "channel_sum: sample too large");
+    if (dtype == RU3D_F32) return chansum_impl<float>(t, out, ws, as_stream(stream));
+    if (dtype == RU3D_BF16) return chansum_impl<bf16>(t, out, ws, as_stream(stream));
+    return ru3d_fail(-1, "channel_sum: bad dtype %d", dtype);
+}
+
+template <typename T>
+static int copy_add_impl(const ru3d_tensor* a, const ru3d_tensor* b, const ru3d_tensor* dst, hipStream_t st) {
+    const int64_t V = (int64_t)a->d * a->h * a->w;
+    const int vec = pick_vec<T>(a->c, {a, b, dst});
+    ChanLoop cl = make_chanloop(V, a->c, vec, 16);
+    dim3 grid(cl.chunks, a->n, (cl.G + cl.Gb - 1) / cl.Gb);
+#define CALL(TT, VV)                                                                                                 \
+    if (b)                                                                                                           \
+        hipLaunchKernelGGL((copy_add_kernel<TT, VV, true>), grid, dim3(256), 0, st, (const TT*)a->ptr, a->ld,         \
+                           (const TT*)b->ptr, b->ld, (TT*)dst->ptr, dst->ld, cl);                                    \
+    else                                                                                                             \
+        hipLaunchKernelGGL((copy_add_kernel<TT, VV, false>), grid, dim3(256), 0, st, (const TT*)a->ptr, a->ld,        \
+                           (const TT*)0, 0, (TT*)dst->ptr, dst->ld, cl)
+    DISPATCH_VEC(T, vec, CALL)
+#undef CALL
+    return ru3d_check_launch("copy_add");
+}
+
+extern "C" int ru3d_copy_channels(const ru3d_tensor* src, const ru3d_tensor* dst, int dtype, void* stream) {
+    RU3D_REQUIRE(tensor_ok(src) && tensor_ok(dst) && same_shape(src, dst), "copy_channels: bad tensors");
+    RU3D_REQUIRE((int64_t)src->d * src->h * src->w < (1ll << 31), "copy_channels: sample too large");
+    if (dtype == RU3D_F32) return copy_add_impl<float>(src, nullptr, dst, as_stream(stream));
+    if (dtype == RU3D_BF16) return copy_add_impl<bf16>(src, nullptr, dst, as_stream(stream));
+    return ru3d_fail(-1, "copy_channels: bad dtype %d", dtype);
+}
+
+extern "C" int ru3d_add(const ru3d_tensor* a, const ru3d_tensor* b, const ru3d_tensor* dst, int dtype,
+                        void* stream) {
+    RU3D_REQUIRE(tensor_ok(a) && tensor_ok(b) && tensor_ok(dst) && same_shape(a, b) && same_shape(a, dst),
+                 "add: bad tensors");
+    RU3D_REQUIRE((int64_t)a->d * a->h * a->w < (1ll << 31), "add: sample too large");
+    if (dtype == RU3D_F32) return copy_add_impl<float>(a, b, dst, as_stream(stream));
+    if (dtype == RU3D_BF16) return copy_add_impl<bf16>(a, b, dst, as_stream(stream));
+    return ru3d_fail(-1, "add: bad dtype %d", dtype);
+}
+
+// fp32 -> storage dtype (small tensors: the 2..4-channel logits gradient)
+template <typename T>
+__global__ void cast_f32_kernel(const float* __restrict__ src, int lds, T* __restrict__ dst, int ldd, int C,
+                                int64_t rows) {
+    const int64_t total = rows * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / C;
+        const int c = (int)(i - r * C);
+        dst[r * ldd + c] = from_f32<T>(src[r * lds + c]);
+    }
+}
+
+extern "C" int ru3d_cast_f32(const ru3d_tensor* src, const ru3d_tensor* dst, int dst_dtype, void* stream) {
+    RU3D_REQUIRE(tensor_ok(src) && tensor_ok(dst) && same_shape(src, dst), "cast_f32: bad tensors");
+    const int64_t rows = nvox(src);
+    int64_t b = (rows * src->c + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (dst_dtype == RU3D_F32)
+        hipLaunchKernelGGL(cast_f32_kernel<float>, dim3((unsigned)b), dim3(256), 0, as_stream(stream),
+                           (const float*)src->ptr, src->ld, (float*)dst->ptr, dst->ld, src->c, rows);
+    else if (dst_dtype == RU3D_BF16)
+        hipLaunchKernelGGL(cast_f32_kernel<bf16>, dim3((unsigned)b), dim3(256), 0, as_stream(stream),
+                           (const float*)src->ptr, src->ld, (bf16*)dst->ptr, dst->ld, src->c, rows);
+    else
+        return ru3d_fail(-1, "cast_f32: bad dtype %d", dst_dtype);
+    return ru3d_check_launch("cast_f32");
+}
+
+// --------------------------------------------------------------------------- dropout mask
+// Counter-based generator (splitmix64 of (seed, offset + i)); one draw per (n, c) volume.
+__global__ void dropout_scale_kernel(float* __restrict__ scale, int count, float p, uint64_t seed,
+                                     uint64_t offset) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint64_t z = seed * 0x9E3779B97F4A7C15ull + (offset + (uint64_t)i + 1) * 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);  // [0,1)
+    scale[i] = (u >= p) ? 1.0f / (1.0f - p) : 0.0f;
+}
+
+extern "C" int ru3d_dropout3d_scale(float* scale, int count, float p, uint64_t seed, uint64_t offset,
+                                    void* stream) {
+    RU3D_REQUIRE(scale && count > 0 && p >= 0.f && p < 1.f, "dropout3d_scale: bad argument");
+    hipLaunchKernelGGL(dropout_scale_kernel, dim3((count + 255) / 256), dim3(256), 0, as_stream(stream), scale, count,
+                       p, seed, offset);
+    return ru3d_check_launch("dropout3d_scale");
+}
+
+// --------------------------------------------------------------------------- NCDHW <-> NDHWC
+// Tiled transpose through LDS: [C][V] <-> [V][C] per sample; 32x32 tiles, padded rows.
+template <typename T, bool TO_CL>
+__global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ ncdhw_in, float* __restrict__ ncdhw_out,
+                                                     const T* __restrict__ cl_in, T* __restrict__ cl_out, int ld,
+                                                     int C, int64_t V) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int64_t v0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x % 32, ty = threadIdx.x / 32;  // 32 x 8
+    if (TO_CL) {
+        for (int r = ty; r < 32; r += 8) {
+            const int c = c0 + r;
+            const int64_t v = v0 + tx;
+            tile[r][tx] = (c < C && v < V) ? ncdhw_in[((int64_t)n * C + c) * V + v] : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int64_t v = v0 + r;
+            const int c = c0 + tx;
+            if (c < C && v < V) cl_out[((int64_t)n * V + v) * ld + c] = from_f32<T>(tile[tx][r]);
+        }
+    } else {
+        for (int r = ty; r < 32; r += 8) {
+            const int64_t v = v0 + r;
+            const int c = c0 + tx;
+            tile[r][tx] = (c < C && v < V) ? to_f32<T>(cl_in[((int64_t)n * V + v) * ld + c]) : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int c = c0 + r;
+            const int64_t v = v0 + tx;
+            if (c < C && v < V) ncdhw_out[((int64_t)n * C + c) * V + v] = tile[tx][r];
+        }
+    }
+}
+
+extern "C" int ru3d_ncdhw_to_ndhwc(const float* src, const ru3d_tensor* dst, int dtype, void* stream) {
+    RU3D_REQUIRE(src && tensor_ok(dst), "ncdhw_to_ndhwc: bad argument");
+    const int64_t V = (int64_t)dst->d * dst->h * dst->w;
+    dim3 grid((unsigned)((V + 31) / 32), (dst->c + 31) / 32, dst->n);
+    if (dtype == RU3D_F32)
+        hipLaunchKernelGGL((repack_kernel<float, true>), grid, dim3(256), 0, as_stream(stream), src, (float*)0,
+                           (const float*)0, (float*)dst->ptr, dst->ld, dst->c, V);
+    else if (dtype == RU3D_BF16)
+        hipLaunchKernelGGL((repack_kernel<bf16, true>), grid, dim3(256), 0, as_stream(stream), src, (float*)0,
+                           (const bf16*)0, (bf16*)dst->ptr, dst->ld, dst->c, V);
+    else
+        return ru3d_fail(-1, "ncdhw_to_ndhwc: bad dtype %d", dtype);
+    return ru3d_check_launch("ncdhw_to_ndhwc");
+}
+
+extern "C" int ru3d_ndhwc_to_ncdhw(const ru3d_tensor* src, float* dst, int dtype, void* stream) {
+    RU3D_REQUIRE(dst && tensor_ok(src), "ndhwc_to_ncdhw: bad argument");
+    const int64_t V = (int64_t)src->d * src->h * src->w;
+    dim3 grid((unsigned)((V + 31) / 32), (src->c + 31) / 32, src->n);
+    if (dtype == RU3D_F32)
+        hipLaunchKernelGGL((repack_kernel<float, false>), grid, dim3(256), 0, as_stream(stream), (const float*)0, dst,
+                           (const float*)src->ptr, (float*)0, src->ld, src->c, V);
+    else if (dtype == RU3D_BF16)
+        hipLaunchKernelGGL((repack_kernel<bf16, false>), grid, dim3(256), 0, as_stream(stream), (const float*)0, dst,
+                           (const bf16*)src->ptr, (bf16*)0, src->ld, src->c, V);
+    else
+        return ru3d_fail(-1, "ndhwc_to_ncdhw: bad dtype %d", dtype);
+    return ru3d_check_launch("ndhwc_to_ncdhw");
+}

@@ -1,0 +1,461 @@
+"""Drop-in `network` module: the reference's U-Net family on the MI355X-native hot path.
+
+Same import surface as the reference `network.py` (class names, constructor signatures, attribute
+names, `state_dict` keys and parameter creation order - so `torch.manual_seed(s); ResUnet3D(...)`
+yields the reference's initial weights and a reference checkpoint loads with strict=True).
+What differs is what runs: the blocks `ResUnet3D` is assembled from (ResBlock, ResBlockStack,
+ConvTrans3D, UpConcat, stem/head convs) execute as hand-written HIP kernels from libru3d.so through
+`_ops` (NDHWC activations, fp32 or bf16 storage, fp32 accumulation).  nn.Conv3d / nn.ConvTranspose3d
+sub-modules are kept as *parameter containers only*; their torch forward is never called on the
+native path.
+
+Reference behaviour implemented (file:line in the reference repo):
+  ResUnet3D 104-132, generate_paired_features 135-141, ConvTrans3D 298-320, UpConcat 323-350,
+  ResBlock 374-416, ResBlockStack 419-449, Unet 470-565.
+Out-of-hot-path variants (ConvBlock*, RecBlock, ResRecBlock, AttBlock, MaxPoolBlock, BatchNorm /
+attention configurations: reference 153-295, 353-371, 452-463) are ordinary torch modules.
+
+Precision: `set_compute_dtype(model, torch.bfloat16)` (or env RU3D_DTYPE=bf16) selects bf16 storage
+with fp32 accumulation; the default float32 is the parity mode.  Logits are always fp32.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+import _native as N
+import _ops as ops
+
+_DEFAULT_DTYPE = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
+                  "bfloat16": torch.bfloat16}[os.environ.get("RU3D_DTYPE", "fp32").lower()]
+
+
+def set_compute_dtype(model, dtype):
+    """Select the activation/weight storage dtype of every native U-Net inside `model`."""
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    for m in model.modules():
+        if isinstance(m, Unet):
+            m.compute_dtype = dtype
+    return model
+
+
+# --------------------------------------------------------------------------- feature plans
+def generate_paired_features(num_pool, num_features):
+    widths = [num_features * (1 << i) for i in range(num_pool + 1)]
+    plan = [[c, c] for c in widths]                       # down path + bottom
+    plan += [[c, c] for c in reversed(widths[:-1])]       # up path
+    return plan
+
+
+def generate_paired_features2(num_pool, num_features):
+    widths = [num_features * (1 << i) for i in range(num_pool + 1)]
+    plan = [[widths[i], widths[i + 1]] for i in range(num_pool)]
+    plan.append([widths[num_pool], widths[num_pool]])
+    plan += [[c, c] for c in reversed(widths[:-1])]
+    return plan
+
+
+def none_fn(level):
+    return {}
+
+
+# --------------------------------------------------------------------------- native eligibility
+def _is_plain_conv3(conv):
+    return (type(conv) is nn.Conv3d and conv.kernel_size == (3, 3, 3) and conv.padding == (1, 1, 1)
+            and conv.dilation == (1, 1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"
+            and conv.stride in ((1, 1, 1), (2, 2, 2)) and conv.bias is not None)
+
+
+def _is_plain_conv1(conv):
+    return (type(conv) is nn.Conv3d and conv.kernel_size == (1, 1, 1) and conv.padding == (0, 0, 0)
+            and conv.dilation == (1, 1, 1) and conv.groups == 1 and conv.stride in ((1, 1, 1), (2, 2, 2))
+            and conv.bias is not None)
+
+
+def _is_plain_in(norm):
+    return (type(norm) is nn.InstanceNorm3d and not norm.affine and not norm.track_running_stats
+            and abs(norm.eps - ops.IN_EPS) < 1e-12)
+
+
+def _is_plain_lrelu(act):
+    return type(act) is nn.LeakyReLU and abs(act.negative_slope - ops.LRELU_SLOPE) < 1e-12
+
+
+# --------------------------------------------------------------------------- generic (torch) blocks
+class ConvBlock(nn.Module):
+    """conv -> dropout -> norm -> nonlin (out of the native hot path; plain torch ops)."""
+
+    def __init__(self, in_channels, out_channels, conv_op=nn.Conv3d,
+                 conv_kwargs={'kernel_size': 3, 'padding': 1},
+                 dropout_op=nn.Dropout3d, dropout_kwargs={'p': 0.5, 'inplace': True},
+                 norm_op=nn.InstanceNorm3d, norm_kwargs={},
+                 nonlin_op=nn.LeakyReLU, nonlin_kwargs={'inplace': True}):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.conv = conv_op(in_channels, out_channels, **conv_kwargs)
+        self.dropout = dropout_op(**dropout_kwargs) if dropout_op else None
+        self.norm = norm_op(out_channels, **norm_kwargs)
+        self.nonlin = nonlin_op(**nonlin_kwargs)
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.dropout:
+            x = self.dropout(x)
+        return self.nonlin(self.norm(x))
+
+
+class ConvBlockStack(nn.Module):
+    def __init__(self, in_channels, out_channels, num_stacks=2, conv_op=nn.Conv3d,
+                 conv_kwargs={'kernel_size': 3, 'padding': 1},
+                 dropout_op=nn.Dropout3d, dropout_kwargs={'p': 0.5, 'inplace': True},
+                 norm_op=nn.InstanceNorm3d, norm_kwargs={},
+                 nonlin_op=nn.LeakyReLU, nonlin_kwargs={'inplace': True}):
+        super().__init__()
+        common = dict(conv_op=conv_op, conv_kwargs=conv_kwargs, dropout_op=dropout_op,
+                      dropout_kwargs=dropout_kwargs, norm_op=norm_op, norm_kwargs=norm_kwargs,
+                      nonlin_op=nonlin_op, nonlin_kwargs=nonlin_kwargs)
+        self.conv_blocks = nn.ModuleList(
+            ConvBlock(in_channels if i == 0 else out_channels, out_channels, **common) for i in range(num_stacks))
+
+    def forward(self, x):
+        for blk in self.conv_blocks:
+            x = blk(x)
+        return x
+
+
+class RecBlock(nn.Module):
+    """Recurrent conv block (R2U-Net style), torch ops."""
+
+    def __init__(self, out_channels, t=2, conv_op=nn.Conv3d, conv_kwargs={'kernel_size': 3, 'padding': 1},
+                 dropout_op=nn.Dropout3d, dropout_kwargs={'p': 0.5, 'inplace': True},
+                 norm_op=nn.InstanceNorm3d, norm_kwargs={},
+                 nonlin_op=nn.LeakyReLU, nonlin_kwargs={'inplace': True}):
+        super().__init__()
+        self.t = t
+        self.out_channels = out_channels
+        self.conv = ConvBlock(out_channels, out_channels, conv_op=conv_op, conv_kwargs=conv_kwargs,
+                              dropout_op=dropout_op, dropout_kwargs=dropout_kwargs, norm_op=norm_op,
+                              norm_kwargs=norm_kwargs, nonlin_op=nonlin_op, nonlin_kwargs=nonlin_kwargs)
+
+    def forward(self, x):
+        out = self.conv(x)
+        for _ in range(self.t):
+            out = self.conv(out + x)
+        return out
+
+
+class ResRecBlock(nn.Module):
+    """Residual recurrent block, torch ops."""
+
+    def __init__(self, in_channels, out_channels, t=2, conv_op=nn.Conv3d,
+                 conv_kwargs={'kernel_size': 3, 'padding': 1},
+                 dropout_op=nn.Dropout3d, dropout_kwargs={'p': 0.5, 'inplace': True},
+                 norm_op=nn.InstanceNorm3d, norm_kwargs={},
+                 nonlin_op=nn.LeakyReLU, nonlin_kwargs={'inplace': True}):
+        super().__init__()
+        self.t = t
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        common = dict(conv_op=conv_op, conv_kwargs=conv_kwargs, dropout_op=dropout_op,
+                      dropout_kwargs=dropout_kwargs, norm_op=norm_op, norm_kwargs=norm_kwargs,
+                      nonlin_op=nonlin_op, nonlin_kwargs=nonlin_kwargs)
+        self.rcnn = nn.Sequential(RecBlock(out_channels, t=t, **common), RecBlock(out_channels, t=t, **common))
+        self.conv = conv_op(in_channels, out_channels, kernel_size=1)
+
+    def forward(self, x):
+        skip = self.conv(x) if self.in_channels != self.out_channels else x
+        return self.rcnn(skip) + skip
+
+
+class AttBlock(nn.Module):
+    """Attention gate sharing one 1x1 conv (torch ops)."""
+
+    def __init__(self, out_channels, conv_op=nn.Conv3d, nonlin_op=nn.LeakyReLU, nonlin_kwargs={'inplace': True}):
+        super().__init__()
+        self.conv = conv_op(out_channels, out_channels, kernel_size=1)
+        self.lrelu = nonlin_op(**nonlin_kwargs)
+        self.active = nn.Sigmoid()
+
+    def forward(self, x, gate):
+        x = self.conv(x)
+        g = self.conv(gate)
+        rate = self.active(self.conv(self.lrelu(x + g)))
+        return x * rate
+
+
+class MaxPoolBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, pool_op=nn.MaxPool3d, pool_kwargs={'kernel_size': 2, 'stride': 2}):
+        super().__init__()
+        self.pool = pool_op(**pool_kwargs)
+
+    def forward(self, x):
+        return self.pool(x)
+
+
+# --------------------------------------------------------------------------- native blocks
+class ConvTrans3D(nn.Module):
+    """ConvTranspose3d(k3,s2,p1) -> zero pad on the far side of each axis -> norm -> nonlin."""
+
+    def __init__(self, in_channels, out_channels, norm_op=nn.InstanceNorm3d, norm_kwargs={},
+                 nonlin_op=nn.LeakyReLU, nonlin_kwargs={'inplace': True}):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.up = nn.Sequential(
+            nn.ConvTranspose3d(in_channels, out_channels, kernel_size=3, stride=2, padding=1),
+            nn.ConstantPad3d(padding=(0, 1, 0, 1, 0, 1), value=0),
+            norm_op(out_channels, **norm_kwargs),
+            nonlin_op(**nonlin_kwargs))
+        self._native = _is_plain_in(self.up[2]) and _is_plain_lrelu(self.up[3])
+
+    def forward(self, x, skip=None):
+        """`skip` is an extension used by UpConcat: returns cat((up(x), skip), dim=1) written in place."""
+        if self._native and x.is_cuda:
+            return ops.UpFn.apply(x, self.up[0].weight, self.up[0].bias, skip)
+        if self._native:
+            N.require_device(x, "ConvTrans3D input")
+        y = self.up(x)
+        return y if skip is None else torch.cat((y, skip), dim=1)
+
+
+class UpConcat(nn.Module):
+    def __init__(self, in_channels, out_channels, conv_trans_op=ConvTrans3D, attention=False,
+                 att_conv_op=nn.Conv3d, norm_op=nn.InstanceNorm3d, norm_kwargs={},
+                 nonlin_op=nn.LeakyReLU, nonlin_kwargs={'inplace': True}):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.attention = attention
+        self.conv_trans = conv_trans_op(in_channels, out_channels, norm_op=norm_op, norm_kwargs=norm_kwargs,
+                                        nonlin_op=nonlin_op, nonlin_kwargs=nonlin_kwargs)
+        if attention:
+            self.att_gate = AttBlock(out_channels, conv_op=att_conv_op, nonlin_op=nonlin_op,
+                                     nonlin_kwargs=nonlin_kwargs)
+
+    def forward(self, x, skip):
+        if not self.attention and isinstance(self.conv_trans, ConvTrans3D):
+            return self.conv_trans(x, skip)          # up-sampled channels first, skip second
+        x = self.conv_trans(x)
+        if self.attention:
+            skip = self.att_gate(skip, x)
+        return torch.cat((x, skip), dim=1)
+
+
+class ResBlock(nn.Module):
+    """conv1(stride) -> dropout -> norm -> nonlin -> conv2 -> norm -> (+ skip) -> nonlin."""
+
+    def __init__(self, in_channels, out_channels, stride=1, conv_op=nn.Conv3d,
+                 conv_kwargs={'kernel_size': 3, 'padding': 1},
+                 dropout_op=nn.Dropout3d, dropout_kwargs={'p': 0.5, 'inplace': True},
+                 norm_op=nn.InstanceNorm3d, norm_kwargs={},
+                 nonlin_op=nn.LeakyReLU, nonlin_kwargs={'inplace': True}):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.stride = stride
+        self.conv1 = conv_op(in_channels, out_channels, stride=stride, **conv_kwargs)
+        self.conv2 = conv_op(out_channels, out_channels, **conv_kwargs)
+        self.dropout = dropout_op(**dropout_kwargs) if dropout_op else None
+        self.norm = norm_op(out_channels, **norm_kwargs)
+        self.nonlin = nonlin_op(**nonlin_kwargs)
+        # always constructed (so it is always in the state_dict), used only when the shapes differ
+        self.skip_conv = conv_op(in_channels, out_channels, kernel_size=1, stride=stride)
+        self._native = (_is_plain_conv3(self.conv1) and _is_plain_conv3(self.conv2)
+                        and _is_plain_conv1(self.skip_conv) and _is_plain_in(self.norm)
+                        and _is_plain_lrelu(self.nonlin)
+                        and (self.dropout is None or type(self.dropout) is nn.Dropout3d))
+        self._forced_keep = None   # tests: inject a recorded [N, C] keep mask instead of drawing one
+
+    @property
+    def uses_skip_conv(self):
+        return self.in_channels != self.out_channels or self.stride != 1
+
+    def _drop_scale(self, x):
+        if self.dropout is None or not self.training:
+            return None
+        p = float(self.dropout.p)
+        n = x.shape[0]
+        if self._forced_keep is not None:
+            keep = self._forced_keep.to(device=x.device, dtype=torch.float32).reshape(-1)
+            return (keep / (1.0 - p)).contiguous()
+        if p == 0.0:
+            return None
+        return ops.dropout_scale(n, self.out_channels, p, x.device)
+
+    def forward(self, x):
+        if self._native and x.is_cuda:
+            skip_w = self.skip_conv.weight if self.uses_skip_conv else None
+            skip_b = self.skip_conv.bias if self.uses_skip_conv else None
+            return ops.ResBlockFn.apply(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                                        skip_w, skip_b, self.stride, self._drop_scale(x))
+        if self._native:
+            N.require_device(x, "ResBlock input")
+        skip = self.skip_conv(x) if self.uses_skip_conv else x
+        x = self.conv1(x)
+        if self.dropout:
+            x = self.dropout(x)
+        x = self.nonlin(self.norm(x))
+        x = self.conv2(x)
+        return self.nonlin(self.norm(x) + skip)
+
+
+class ResBlockStack(nn.Module):
+    def __init__(self, in_channels, out_channels, stride=1, num_stacks=2, conv_op=nn.Conv3d,
+                 conv_kwargs={'kernel_size': 3, 'padding': 1},
+                 dropout_op=nn.Dropout3d, dropout_kwargs={'p': 0.5, 'inplace': True},
+                 norm_op=nn.InstanceNorm3d, norm_kwargs={},
+                 nonlin_op=nn.LeakyReLU, nonlin_kwargs={'inplace': True}):
+        super().__init__()
+        common = dict(conv_op=conv_op, conv_kwargs=conv_kwargs, dropout_op=dropout_op,
+                      dropout_kwargs=dropout_kwargs, norm_op=norm_op, norm_kwargs=norm_kwargs,
+                      nonlin_op=nonlin_op, nonlin_kwargs=nonlin_kwargs)
+        self.res_blocks = nn.ModuleList(
+            ResBlock(in_channels if i == 0 else out_channels, out_channels, stride=stride if i == 0 else 1,
+                     **common) for i in range(num_stacks))
+
+    def forward(self, x):
+        for blk in self.res_blocks:
+            x = blk(x)
+        return x
+
+
+class Unet(nn.Module):
+    """Generic encoder/decoder assembler: stem conv, [encode_i, pool_i] x P, bottom encode,
+    [up_i(x, skip_i), decode_i] x P (deepest first), 1x1x1 head.  Block classes are constructor
+    arguments, exactly as in the reference."""
+
+    def __init__(self, in_channels, out_channels, paired_features,
+                 pool_block=MaxPoolBlock, pool_kwargs={}, pool_kwargs_fn=none_fn,
+                 up_block=UpConcat, up_kwargs={}, up_kwargs_fn=none_fn,
+                 encode_block=ConvBlockStack, encode_kwargs={}, encode_kwargs_fn=none_fn,
+                 decode_block=ConvBlockStack, decode_kwargs={}, decode_kwargs_fn=none_fn,
+                 conv_op=nn.Conv3d):
+        super().__init__()
+        num_pairs = len(paired_features)
+        assert (num_pairs % 2) == 1, 'Number of paired features must be odd number.'
+        self.num_pool = num_pairs // 2
+        assert self.num_pool > 0, 'At least one pool.'
+        pf = paired_features
+        pools, ups, encs, decs = [], [], [], []
+        # construction order (pool, up, encode, decode per level; then bottom, stem, head) is part of
+        # the contract: it fixes the RNG stream of the default initialisation.
+        for i in range(self.num_pool):
+            mirror = num_pairs - i - 1
+            pools.append(pool_block(pf[i][1], pf[i + 1][0], **pool_kwargs_fn(i), **pool_kwargs))
+            ups.append(up_block(pf[mirror - 1][1], pf[mirror][0], **up_kwargs_fn(i), **up_kwargs))
+            encs.append(encode_block(pf[i][0], pf[i][1], **encode_kwargs_fn(i), **encode_kwargs))
+            decs.append(decode_block(pf[mirror][0] + pf[i][1], pf[mirror][1], **decode_kwargs_fn(i),
+                                     **decode_kwargs))
+        encs.append(encode_block(pf[self.num_pool][0], pf[self.num_pool][1], **encode_kwargs_fn(self.num_pool),
+                                 **encode_kwargs))
+        self.pool_blocks = nn.ModuleList(pools)
+        self.up_blocks = nn.ModuleList(ups)
+        self.encode_blocks = nn.ModuleList(encs)
+        self.decode_blocks = nn.ModuleList(decs)
+        self.conv = conv_op(in_channels, pf[0][0], kernel_size=3, padding=1)
+        self.fc = conv_op(pf[num_pairs - 1][1], out_channels, kernel_size=1)
+        self.compute_dtype = _DEFAULT_DTYPE
+        self._native_io = _is_plain_conv3(self.conv) and _is_plain_conv1(self.fc)
+
+    def _stem(self, x):
+        if self._native_io and x.is_cuda:
+            return ops.ConvFn.apply(x, self.conv.weight, self.conv.bias, 1, self.compute_dtype, self.compute_dtype)
+        if self._native_io:
+            N.require_device(x, "Unet input")
+        return self.conv(x)
+
+    def _head(self, x):
+        if self._native_io and x.is_cuda:
+            return ops.ConvFn.apply(x, self.fc.weight, self.fc.bias, 1, x.dtype, torch.float32)
+        return self.fc(x)
+
+    def forward(self, x):
+        x = self._stem(x)
+        skips = []
+        for i in range(self.num_pool):
+            x = self.encode_blocks[i](x)
+            skips.append(x)
+            x = self.pool_blocks[i](x)
+        x = self.encode_blocks[-1](x)
+        for i in reversed(range(self.num_pool)):
+            x = self.up_blocks[i](x, skips[i])
+            x = self.decode_blocks[i](x)
+        return self._head(x)
+
+
+# --------------------------------------------------------------------------- model zoo
+def _stacks_by_level(level):
+    return {'num_stacks': max(level, 1)}
+
+
+class _UnetWrapper(nn.Module):
+    def forward(self, x):
+        return self.net(x)
+
+
+class ResUnet3D(_UnetWrapper):
+    """Residual 3D U-Net: ResBlockStack encoders (max(level,1) blocks), stride-2 ResBlock pooling,
+    ConvTrans3D up-sampling + concat, ResBlock decoders.  This is the model every training script uses."""
+
+    def __init__(self, num_pool=4, num_features=30, in_channels=1, out_channels=1):
+        super().__init__()
+        self.num_pool = num_pool
+        self.num_features = num_features
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.net = Unet(in_channels=in_channels, out_channels=out_channels,
+                        paired_features=generate_paired_features(num_pool, num_features),
+                        pool_block=ResBlock, pool_kwargs={'stride': 2},
+                        encode_block=ResBlockStack, encode_kwargs_fn=_stacks_by_level,
+                        decode_block=ResBlock)
+
+
+class ResAttrUnet3D(_UnetWrapper):
+    """ResUnet3D with attention-gated skips (attention gate runs as torch ops)."""
+
+    def __init__(self, num_pool=4, num_features=30, in_channels=1, out_channels=1):
+        super().__init__()
+        self.num_pool = num_pool
+        self.num_features = num_features
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.net = Unet(in_channels=in_channels, out_channels=out_channels,
+                        paired_features=generate_paired_features(num_pool, num_features),
+                        pool_block=ResBlock, pool_kwargs={'stride': 2}, up_kwargs={'attention': True},
+                        encode_block=ResBlockStack, encode_kwargs_fn=_stacks_by_level,
+                        decode_block=ResBlock)
+
+
+class ResAttrUnet3D2(_UnetWrapper):
+    """Fixed 30/60/120/240/320 channel plan with attention-gated skips."""
+
+    def __init__(self, in_channels=1, out_channels=1):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        widths = [30, 60, 120, 240, 320]
+        plan = [[c, c] for c in widths] + [[320, 320]] + [[c, c] for c in reversed(widths)]
+        self.net = Unet(in_channels=in_channels, out_channels=out_channels, paired_features=plan,
+                        pool_block=ResBlock, pool_kwargs={'stride': 2}, up_kwargs={'attention': True},
+                        encode_block=ResBlockStack, encode_kwargs_fn=_stacks_by_level,
+                        decode_block=ResBlock)
+
+
+class ResAttrBNUnet3D(_UnetWrapper):
+    """BatchNorm + attention variant (torch ops: BatchNorm is outside the native hot path)."""
+
+    def __init__(self, num_pool=4, num_features=30, in_channels=1, out_channels=1):
+        super().__init__()
+        self.num_pool = num_pool
+        self.num_features = num_features
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        bn = {'norm_op': nn.BatchNorm3d}
+        self.net = Unet(in_channels=in_channels, out_channels=out_channels,
+                        paired_features=generate_paired_features(num_pool, num_features),
+                        pool_block=ResBlock, pool_kwargs={'stride': 2, **bn},
+                        up_kwargs={'attention': True, **bn},
+                        encode_block=ResBlockStack, encode_kwargs=bn, encode_kwargs_fn=_stacks_by_level,
+                        decode_block=ResBlock, decode_kwargs=bn)

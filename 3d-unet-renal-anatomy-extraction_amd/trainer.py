@@ -1,0 +1,328 @@
+"""Drop-in `trainer` module: host-side driver of the native training step.
+
+Keeps the reference `Trainer` surface (reference trainer.py:415-634: constructor arguments,
+`fit(num_epochs, save_dir, use_amp, opt_level)`, `batch_loop`, `save_checkpoint` / `load_checkpoint`
+with the same checkpoint keys, `get_lr` / `set_lr` / `summary`, `Subset`) and the pre-refactor
+spelling the oldest script uses (reference run_train.py:71-96: `Trainer(criterion=, tr_transform=,
+vd_transform=)`, `fit(dataset, batch_size=, epochs=, ...)`, `save` / `load`).
+
+What changes underneath:
+  * `use_amp=True` selects bf16 storage / fp32 accumulation of the native kernels (the reference
+    patched fp16 convs in through apex O1, trainer.py:538-542); no loss scaling is needed for bf16.
+  * per-step `.item()` calls are deferred: the loss/metric scalars stay on the device and are read
+    back once per `sync_every` steps (default: every step, the reference's behaviour), so the GPU
+    is not drained between kernels.  The NaN rule is the reference's: a NaN step is excluded from
+    the epoch mean but its optimizer step has already been applied (trainer.py:496 vs 505-506).
+  * one process per GPU: when torch.distributed is initialised, gradients are averaged across
+    ranks by `parallel.GradSync` (bucketed RCCL all-reduce on a side stream, overlapped with the
+    rest of backward) and each rank draws its own samples.
+  * apex / torchsummary / tensorboard / nibabel are optional.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+from torch.optim import lr_scheduler
+
+try:
+    from tqdm import tqdm
+except Exception:  # pragma: no cover
+    tqdm = None
+try:
+    from torch.utils.tensorboard import SummaryWriter
+except Exception:
+    SummaryWriter = None
+
+from loss import dice  # noqa: F401  (re-exported like the reference: trainer.dice)
+
+
+class _NullBar:
+    def __init__(self, *a, **k):
+        pass
+
+    def reset(self, total=None):
+        pass
+
+    def set_description(self, *a, **k):
+        pass
+
+    def set_postfix(self, *a, **k):
+        pass
+
+    def update(self, *a, **k):
+        pass
+
+    def close(self):
+        pass
+
+
+class Subset(torch.utils.data.Subset):
+    """Index subset that applies a transform to each fetched case."""
+
+    def __init__(self, dataset, indices, transform):
+        super().__init__(dataset, indices)
+        self.transform = transform
+
+    def __getitem__(self, idx):
+        case = self.dataset[self.indices[idx]]
+        return self.transform(case) if self.transform else case
+
+
+def _dist_ready():
+    return torch.distributed.is_available() and torch.distributed.is_initialized() \
+        and torch.distributed.get_world_size() > 1
+
+
+class Trainer():
+    def __init__(self, model, optimizer, loss=None, dataset=None, batch_size=10,
+                 dataloader_kwargs={'num_workers': 2, 'pin_memory': True},
+                 valid_split=0.2, num_samples=None, metrics=None, scheduler=None,
+                 train_transform=None, valid_transform=None,
+                 criterion=None, tr_transform=None, vd_transform=None, sync_every=1, progress=True):
+        self.model = model
+        self.optimizer = optimizer
+        self.loss = loss if loss is not None else criterion
+        if self.loss is None:
+            raise TypeError("Trainer needs a loss (loss=... or the legacy criterion=...)")
+        self.dataset = dataset
+        self.metrics = metrics
+        self.scheduler = scheduler
+        self.train_transform = train_transform if train_transform is not None else tr_transform
+        self.valid_transform = valid_transform if valid_transform is not None else vd_transform
+        self.batch_size = batch_size
+        self.dataloader_kwargs = {'batch_size': batch_size, **dataloader_kwargs}
+        self.num_samples = num_samples
+        self.valid_split = valid_split
+        self.train_indices, self.valid_indices = [], []
+        if dataset is not None:
+            self._split_indices()
+        self.device = next(model.parameters()).device
+        self.best_result = {'loss': float('inf')}
+        self.current_epoch = 0
+        self.patience_counter = 0
+        self.amp_state_dict = None
+        self.use_amp = False
+        self.save_dir = None
+        self.num_epochs = 0
+        self.sync_every = max(1, int(sync_every))
+        self.progress = progress
+        self.progress_bar = _NullBar()
+        self._grad_sync = None
+
+    # ------------------------------------------------------------------ small helpers
+    def _split_indices(self):
+        # same draw as the reference: global numpy RNG, floor(valid_split * len) validation cases
+        size = len(self.dataset)
+        indices = list(range(size))
+        split = int(np.floor(self.valid_split * size))
+        np.random.shuffle(indices)
+        self.train_indices = indices[split:]
+        self.valid_indices = indices[:split]
+
+    def get_lr(self, idx=0):
+        return self.optimizer.param_groups[idx]['lr']
+
+    def set_lr(self, lr, idx=0):
+        self.optimizer.param_groups[idx]['lr'] = lr
+
+    def summary(self, input_shape):
+        try:
+            from torchsummary import summary as _summary
+            return _summary(self.model, input_shape)
+        except ImportError:
+            total = sum(p.numel() for p in self.model.parameters())
+            trainable = sum(p.numel() for p in self.model.parameters() if p.requires_grad)
+            text = "%s: %d parameters (%d trainable), input %s" % (type(self.model).__name__, total, trainable,
+                                                                   tuple(input_shape))
+            print(text)
+            return text
+
+    # ------------------------------------------------------------------ the step
+    def _flush(self, pending, results):
+        """Read back deferred device scalars (one sync for the whole group)."""
+        if not pending:
+            return None
+        keys = list(pending[0].keys())
+        stacked = torch.stack([torch.stack([p[k].detach().float().reshape(()) for k in keys]) for p in pending])
+        values = stacked.cpu().numpy()
+        last = None
+        for row in values:
+            result = {k: float(v) for k, v in zip(keys, row)}
+            if not math.isnan(result['loss']):
+                results.append(result)
+            last = result
+        pending.clear()
+        return last
+
+    def batch_loop(self, data_loader, is_train=True):
+        results, pending = [], []
+        self.progress_bar.reset(len(data_loader))
+        self.progress_bar.set_description("Epoch %d/%d (LR %.2g)" % (self.current_epoch + 1, self.num_epochs,
+                                                                     self.get_lr()))
+        for batch_idx, batch in enumerate(data_loader):
+            x = batch['image'].to(self.device, non_blocking=True)
+            y = batch['label'].to(self.device, non_blocking=True)
+            if is_train:
+                self.model.train()
+                y_pred = self.model(x)
+            else:
+                self.model.eval()
+                with torch.no_grad():
+                    y_pred = self.model(x)
+            loss = self.loss(y_pred, y)
+            if is_train:
+                self.optimizer.zero_grad()
+                if self._grad_sync is not None:
+                    self._grad_sync.begin_step()
+                loss.backward()
+                if self._grad_sync is not None:
+                    self._grad_sync.finish_step()
+                self.optimizer.step()
+            scalars = {'loss': loss}
+            if self.metrics is not None:
+                with torch.no_grad():
+                    for key, metric_fn in self.metrics.items():
+                        scalars[key] = metric_fn(y_pred, y)
+            pending.append({k: (v if torch.is_tensor(v) else torch.tensor(float(v))) for k, v in scalars.items()})
+            if len(pending) >= self.sync_every:
+                last = self._flush(pending, results)
+                self.progress_bar.set_postfix(last)
+            self.progress_bar.update()
+        self._flush(pending, results)
+
+        mean_result = {}
+        if results:
+            for key in results[0].keys():
+                mean_result[key] = float(np.mean(np.array([r[key] for r in results])))
+        else:
+            mean_result = {'loss': float('nan')}
+        name = 'train' if is_train else 'valid'
+        if self.save_dir is not None and SummaryWriter is not None:
+            writer = SummaryWriter(self.save_dir)
+            for key, value in mean_result.items():
+                writer.add_scalar('%s/%s' % (key, name), value, self.current_epoch)
+            writer.close()
+        return mean_result
+
+    # ------------------------------------------------------------------ loaders
+    def _loader(self, indices, transform, num_samples, shuffle):
+        subset = Subset(self.dataset, indices, transform)
+        kwargs = dict(self.dataloader_kwargs)
+        if num_samples is not None:
+            sampler = torch.utils.data.RandomSampler(subset, True, num_samples)
+            return torch.utils.data.DataLoader(subset, sampler=sampler, **kwargs)
+        return torch.utils.data.DataLoader(subset, shuffle=shuffle, **kwargs)
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, *args, num_epochs=None, save_dir=None, use_amp=False, opt_level='O1', **legacy):
+        """fit(num_epochs=10, save_dir=None, use_amp=False, opt_level='O1')  - current API
+        fit(dataset, batch_size=, epochs=, num_samples=, valid_split=, log_dir=, save_dir=, save_last=,
+            save_best=, num_workers=, pin_memory=)                          - run_train.py spelling"""
+        save_last = legacy.pop('save_last', True)
+        save_best = legacy.pop('save_best', True)
+        if args and not isinstance(args[0], (int, np.integer)):
+            self.dataset = args[0]
+            args = args[1:]
+            if 'valid_split' in legacy:
+                self.valid_split = legacy.pop('valid_split')
+            self._split_indices()
+        if args:
+            num_epochs = args[0]
+            if len(args) > 1:
+                save_dir = args[1]
+        if 'epochs' in legacy:
+            num_epochs = legacy.pop('epochs')
+        if num_epochs is None:
+            num_epochs = 10
+        if 'batch_size' in legacy:
+            self.batch_size = legacy.pop('batch_size')
+            self.dataloader_kwargs['batch_size'] = self.batch_size
+        for key in ('num_workers', 'pin_memory'):
+            if key in legacy:
+                self.dataloader_kwargs[key] = legacy.pop(key)
+        if 'num_samples' in legacy:
+            self.num_samples = legacy.pop('num_samples')
+        log_dir = legacy.pop('log_dir', None)
+        if save_dir is None and log_dir is not None:
+            save_dir = log_dir
+        if legacy:
+            raise TypeError("fit() got unexpected arguments %s" % sorted(legacy))
+        if self.dataset is None:
+            raise ValueError("Trainer.fit: no dataset (pass dataset= to Trainer or as the first fit() argument)")
+
+        self.num_epochs = num_epochs
+        self.use_amp = use_amp
+        self.save_dir = save_dir
+        if use_amp:
+            # apex O1 (fp16 convs) in the reference; here: bf16 storage + fp32 accumulate in the HIP kernels
+            import network
+            network.set_compute_dtype(self.model, torch.bfloat16)
+        if _dist_ready() and self._grad_sync is None:
+            from parallel import GradSync
+            self._grad_sync = GradSync(self.model)
+        self.progress_bar = tqdm(total=0) if (tqdm is not None and self.progress) else _NullBar()
+
+        train_loader = self._loader(self.train_indices, self.train_transform, self.num_samples, True)
+        valid_loader = None
+        if len(self.valid_indices) > 0:
+            n_valid = round(self.num_samples * self.valid_split) if self.num_samples is not None else None
+            valid_loader = self._loader(self.valid_indices, self.valid_transform, n_valid, False)
+
+        for epoch in range(self.current_epoch, num_epochs):
+            self.current_epoch = epoch
+            result = self.batch_loop(train_loader, is_train=True)
+            if valid_loader is not None:
+                result = self.batch_loop(valid_loader, is_train=False)
+            if self.scheduler is not None:
+                if isinstance(self.scheduler, lr_scheduler.ReduceLROnPlateau):
+                    self.scheduler.step(result['loss'])
+                else:
+                    self.scheduler.step()
+            if result['loss'] < self.best_result['loss'] - 1e-3:
+                self.best_result = result
+                if save_dir is not None and save_best:
+                    self.save_checkpoint(save_dir + '-best.pt')
+            if save_dir is not None and save_last:
+                self.save_checkpoint(save_dir + '-last.pt')
+        self.progress_bar.close()
+        return self.best_result
+
+    # ------------------------------------------------------------------ checkpoints
+    def save_checkpoint(self, file_path):
+        checkpoint = {'model_state_dict': self.model.state_dict(),
+                      'optimizer_state_dict': self.optimizer.state_dict(),
+                      'current_epoch': self.current_epoch,
+                      'train_indices': self.train_indices,
+                      'valid_indices': self.valid_indices,
+                      'best_result': self.best_result}
+        if self.scheduler is not None:
+            checkpoint['scheduler_state_dict'] = self.scheduler.state_dict()
+        if self.use_amp:
+            # apex's loss-scaler state in the reference; bf16 needs none - kept so the key set matches
+            checkpoint['amp_state_dict'] = self.amp_state_dict or {'ru3d': 'bf16'}
+        directory = os.path.dirname(file_path)
+        if directory:
+            os.makedirs(directory, exist_ok=True)
+        if not _dist_ready() or torch.distributed.get_rank() == 0:
+            torch.save(checkpoint, file_path)
+
+    def load_checkpoint(self, file_path):
+        try:
+            checkpoint = torch.load(file_path, map_location=self.device, weights_only=False)
+        except TypeError:  # older torch without weights_only
+            checkpoint = torch.load(file_path, map_location=self.device)
+        self.model.load_state_dict(checkpoint['model_state_dict'])
+        self.optimizer.load_state_dict(checkpoint['optimizer_state_dict'])
+        self.current_epoch = checkpoint['current_epoch'] + 1
+        self.train_indices = checkpoint['train_indices']
+        self.valid_indices = checkpoint['valid_indices']
+        self.best_result = checkpoint['best_result']
+        if 'amp_state_dict' in checkpoint:
+            self.amp_state_dict = checkpoint['amp_state_dict']
+        if 'scheduler_state_dict' in checkpoint and self.scheduler is not None:
+            self.scheduler.load_state_dict(checkpoint['scheduler_state_dict'])
+
+    # run_train.py spelling
+    save = save_checkpoint
+    load = load_checkpoint

@@ -1,0 +1,167 @@
+/*
+ * ru3d.h - C ABI of the MI355X-native 3D U-Net training hot path (libru3d.so).
+ *
+ * The reference (icrdr/3D-UNet-Renal-Anatomy-Extraction) has no FFI of its own: its hot path is
+ * entered through `nn.Module.__call__` and every arithmetic op is delegated to torch.nn.  This
+ * header is the boundary the build introduces *beneath* the reference's Python classes
+ * (network.py / loss.py / trainer.py keep their names and signatures); each entry point cites the
+ * reference call site whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - plain C only: scalars, raw device pointers, explicit shapes; no C++/torch types.
+ *  - the CALLER owns every buffer, including workspaces (sizes from the *_workspace_bytes calls);
+ *    the library never allocates or frees device memory and keeps no mutable global state.
+ *  - activations are NDHWC ("channels last") in HBM: element (n,d,h,w,c) of a tensor lives at
+ *    ptr[(((n*D+d)*H+h)*W+w)*ld + c]; `ld` (>= c) is the voxel pitch in elements, so a tensor can be
+ *    a channel slice of a wider buffer (this is how the skip-concat is written in place).
+ *  - every call only enqueues work on `stream` (a hipStream_t passed as void*; NULL = default
+ *    stream).  No call synchronises the device.
+ *  - return value: 0 = OK; < 0 = invalid argument / unsupported shape (see ru3d_last_error());
+ *    > 0 = hipError_t from the launch.  Never throws, never exits.
+ *  - thread safety: re-entrant; the error string is thread-local (PyTorch runs backward on its own
+ *    autograd thread).
+ */
+#ifndef RU3D_H
+#define RU3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RU3D_VERSION 100
+
+/* storage dtypes of activations / packed weights (accumulation is always fp32) */
+enum { RU3D_F32 = 0, RU3D_BF16 = 1 };
+
+/* label dtypes accepted by the loss kernels (reference passes int64: loss.py:27) */
+enum { RU3D_LABEL_I64 = 0, RU3D_LABEL_U8 = 1 };
+
+/* which reference weight tensor a packed weight is made from, and for which kernel */
+enum {
+    RU3D_ROLE_CONV_FWD = 0,    /* nn.Conv3d weight [Cout][Cin][k^3]          -> forward          */
+    RU3D_ROLE_CONV_DGRAD = 1,  /* nn.Conv3d weight                            -> input gradient   */
+    RU3D_ROLE_CONVT_FWD = 2,   /* nn.ConvTranspose3d weight [Cin][Cout][k^3]  -> forward          */
+    RU3D_ROLE_CONVT_DGRAD = 3  /* nn.ConvTranspose3d weight                   -> input gradient   */
+};
+
+/* loss kinds: which reference module the finalize step reproduces */
+enum {
+    RU3D_LOSS_HYBIRD = 0,   /* loss.py:196-254 HybirdLoss                    */
+    RU3D_LOSS_DICELOSS = 1, /* loss.py:123-166 DiceLoss                      */
+    RU3D_LOSS_FOCAL = 2,    /* loss.py:169-193 FocalLoss (+ focal_loss :51)  */
+    RU3D_LOSS_DICE = 3      /* loss.py:85-120  Dice (metric)                 */
+};
+
+typedef struct ru3d_tensor {
+    void* ptr;          /* device pointer to element (0,0,0,0,0)        */
+    int32_t n, d, h, w; /* batch and spatial extents                     */
+    int32_t c;          /* channels                                      */
+    int32_t ld;         /* voxel pitch in elements (>= c)                */
+} ru3d_tensor;
+
+int ru3d_version(void);
+/* thread-local, valid until the next failing call on this thread */
+const char* ru3d_last_error(void);
+
+/* ------------------------------------------------------------------ weights ----------------- */
+/* Number of bytes of the packed form of a weight (layout is private to the library and depends on
+ * (cin, cout, k, dtype, role)). */
+size_t ru3d_packed_weight_bytes(int cout, int cin, int k, int role, int dtype);
+/* src: fp32 weight in the reference's layout (state_dict tensor, contiguous).  dst: packed. */
+int ru3d_pack_weight(const float* src, void* dst, int cout, int cin, int k, int role, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ convolutions ------------ */
+/* nn.Conv3d(k in {1,3}, stride in {1,2}, padding=k/2) forward (network.py:394-395,403,541-547).
+ * y = conv(x) + bias (+ res).  bias (fp32 [Cout]) and res may be NULL.  y_dtype may be RU3D_F32
+ * while x is bf16 (the logits head). */
+int ru3d_conv3d_fwd(const ru3d_tensor* x, const void* w_packed, const float* bias, const ru3d_tensor* res,
+                    const ru3d_tensor* y, int k, int stride, int dtype, int y_dtype, void* stream);
+/* input gradient of the same conv: dx = conv_dgrad(dy) (+ res).  w_packed made with ROLE_CONV_DGRAD. */
+int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* res,
+                      const ru3d_tensor* dx, int k, int stride, int dtype, void* stream);
+/* weight gradient, written as fp32 in the reference layout [Cout][Cin][k^3] (param.grad). */
+size_t ru3d_conv3d_wgrad_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* dy, int k, int stride, int dtype);
+int ru3d_conv3d_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, float* dw, void* ws, size_t ws_bytes,
+                      int k, int stride, int dtype, void* stream);
+
+/* nn.ConvTranspose3d(k3,s2,p1) followed by ConstantPad3d((0,1,0,1,0,1),0) (network.py:312-314):
+ * y has extents 2*x.{d,h,w}; its far planes are written as exact zeros (no bias there). */
+int ru3d_convtranspose3d_k3s2p1_fwd(const ru3d_tensor* x, const void* w_packed, const float* bias,
+                                    const ru3d_tensor* y, int dtype, void* stream);
+/* dy must have zero far planes (ru3d_in_lrelu_bwd(zero_far=1) guarantees it). */
+int ru3d_convtranspose3d_k3s2p1_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* dx,
+                                      int dtype, void* stream);
+size_t ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* dy, int dtype);
+/* dw fp32 in the reference layout [Cin][Cout][27]. */
+int ru3d_convtranspose3d_k3s2p1_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, float* dw, void* ws,
+                                      size_t ws_bytes, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ InstanceNorm + LeakyReLU - */
+size_t ru3d_reduce_workspace_bytes(const ru3d_tensor* t);
+/* nn.InstanceNorm3d(eps, affine=False) statistics (network.py:401,414), with the preceding
+ * nn.Dropout3d folded in: drop_scale[n*C+c] in {0, 1/(1-p)} or NULL.
+ * Outputs mean[n*C+c] of the raw y and scale = s / sqrt(s^2 * var + eps), so that
+ * x_hat = (y - mean) * scale equals InstanceNorm(Dropout3d(y)). */
+int ru3d_instnorm_stats(const ru3d_tensor* y, const float* drop_scale, float* mean, float* scale,
+                        void* ws, size_t ws_bytes, float eps, int dtype, void* stream);
+/* out = LeakyReLU((y - mean) * scale (+ res), slope)  (network.py:414,416; 315-316). */
+int ru3d_in_lrelu_fwd(const ru3d_tensor* y, const float* mean, const float* scale, const ru3d_tensor* res,
+                      const ru3d_tensor* out, float slope, int dtype, void* stream);
+/* backward of the above: given gout = dL/dout, writes dy = dL/dy and (optionally, when the forward
+ * had a residual) gpre = gout * LeakyReLU'(out) = dL/dres.  zero_far=1 additionally zeroes the last
+ * plane of each spatial axis of dy (the constant-pad planes of ConvTrans3D). */
+int ru3d_in_lrelu_bwd(const ru3d_tensor* gout, const ru3d_tensor* out, const ru3d_tensor* y, const float* mean,
+                      const float* scale, const ru3d_tensor* dy, const ru3d_tensor* gpre, void* ws,
+                      size_t ws_bytes, float slope, int zero_far, int dtype, void* stream);
+/* out[c] = sum over n,d,h,w of t (bias gradients). */
+int ru3d_channel_sum(const ru3d_tensor* t, float* out, void* ws, size_t ws_bytes, int dtype, void* stream);
+/* nn.Dropout3d(p) channel mask (network.py:397-398,412-413): scale[n*C+c] = keep ? 1/(1-p) : 0,
+ * counter-based RNG keyed by (seed, offset). */
+int ru3d_dropout3d_scale(float* scale, int count, float p, uint64_t seed, uint64_t offset, void* stream);
+
+/* ------------------------------------------------------------------ layout helpers ---------- */
+/* dst[...,c] = src[...,c] for c < src.c (torch.cat along channels, network.py:350, written in place). */
+int ru3d_copy_channels(const ru3d_tensor* src, const ru3d_tensor* dst, int dtype, void* stream);
+/* dst = src + add, same shape (gradient accumulation of the skip branch). */
+int ru3d_add(const ru3d_tensor* a, const ru3d_tensor* b, const ru3d_tensor* dst, int dtype, void* stream);
+/* dst (dtype `dst_dtype`) = src (fp32), same shape: fp32 logits-gradient -> storage dtype. */
+int ru3d_cast_f32(const ru3d_tensor* src, const ru3d_tensor* dst, int dst_dtype, void* stream);
+/* NCDHW fp32 (reference tensor layout) -> NDHWC `dtype`, and back. */
+int ru3d_ncdhw_to_ndhwc(const float* src, const ru3d_tensor* dst, int dtype, void* stream);
+int ru3d_ndhwc_to_ncdhw(const ru3d_tensor* src, float* dst, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ loss -------------------- */
+/* Fused softmax + focal + Tversky sums (loss.py:7-48, 51-82, 218-254): one pass over logits+labels.
+ * logits: fp32, element (n, c, v) at logits[n*stride_n + c*stride_c + v*stride_v] (covers both the
+ * NDHWC tensor the network writes and a plain NCDHW tensor).  labels: [N*V] int64 or uint8.
+ * state: caller-owned device buffer of ru3d_loss_state_bytes(C) bytes; receives the class sums, the
+ * backward coefficients and the number of out-of-range labels.  loss_out: 1 fp32 on device.
+ * C == 1 uses sigmoid with an all-ones one-hot (what F.one_hot(target, 1) yields for valid targets). */
+size_t ru3d_loss_state_bytes(int num_classes);
+size_t ru3d_loss_workspace_bytes(int n, int64_t v, int num_classes);
+int ru3d_loss_fwd(const float* logits, int64_t stride_n, int64_t stride_c, int64_t stride_v, const void* labels,
+                  int label_dtype, int n, int64_t v, int num_classes, int kind, float gamma, const float* weight_v,
+                  float alpha, float beta, float smooth, void* state, float* loss_out, void* ws, size_t ws_bytes,
+                  void* stream);
+/* dlogits (same strides as logits; dtype f32 or bf16) = grad_out[0] * dLoss/dlogits. */
+int ru3d_loss_bwd(const float* logits, int64_t stride_n, int64_t stride_c, int64_t stride_v, const void* labels,
+                  int label_dtype, int n, int64_t v, int num_classes, float gamma, const void* state,
+                  const float* grad_out, void* dlogits, int dlogits_dtype, void* stream);
+/* functional `dice` of loss.py:32-48 on two flat fp32 vectors (used by trainer.evaluate_case). */
+int ru3d_tversky(const float* p, const float* g, int64_t count, float alpha, float beta, float smooth,
+                 float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ optimizer --------------- */
+/* torch.optim.Adam step (nb_train_iia.py:18 defaults), fused over one flat fp32 parameter run.
+ * grad may be bf16/f32 (grad_dtype); bias corrections are passed in by the host. */
+int ru3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                   float lr, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
+                   float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RU3D_H */

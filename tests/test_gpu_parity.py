@@ -1,0 +1,368 @@
+"""Parity of the HIP path (through the C ABI + drop-in modules) against the golden fixtures produced by
+the reference and against the CPU oracle.  Needs a real MI355X: run with `-m gpu`.
+
+Tolerances (fp32 parity mode): logits/activations 1e-4 abs (values are O(1)), gradients 1e-3 relative
+to the tensor's max magnitude; argmax masks must be bit-identical on the fixtures.  bf16 mode
+tolerances are stated in the bf16 tests."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():  # collected on CPU boxes too; everything here is skipped there
+    pytest.skip("no HIP device", allow_module_level=True)
+
+import _native as N  # noqa: E402
+import _ops as ops  # noqa: E402
+import loss as L  # noqa: E402
+import network  # noqa: E402
+from oracle import unet_oracle as O  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _sub(z, prefix):
+    return {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+
+
+def _close(a, b, rtol, atol=0.0, what=""):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    lim = atol + rtol * max(b.abs().max().item(), 1e-30)
+    assert err <= lim, "%s: max err %.3e > %.3e" % (what, err, lim)
+
+
+def test_library_loaded_from_tree():
+    assert N.lib.ru3d_version() == 100
+    assert os.path.dirname(N.LIB_PATH).endswith("3d-unet-renal-anatomy-extraction_amd")
+
+
+# --------------------------------------------------------------------------- per-block fixtures (G3)
+def _build(tag):
+    if tag.startswith("res_"):
+        cin, cout, stride = {"res_encode_c8": (8, 8, 1), "res_pool_c8_16": (8, 16, 2),
+                             "res_pool_odd_c3_8": (3, 8, 2), "res_decode_c16_8": (16, 8, 1),
+                             "res_encode_c30": (30, 30, 1), "res_encode_c32": (32, 32, 1)}[tag]
+        return network.ResBlock(cin, cout, stride=stride)
+    if tag == "stack3_c8":
+        return network.ResBlockStack(8, 8, num_stacks=3)
+    if tag == "convtrans_c16_8":
+        return network.ConvTrans3D(16, 8)
+    if tag == "convtrans_c32_16":
+        return network.ConvTrans3D(32, 16)
+    if tag == "upconcat_c16_8":
+        return network.UpConcat(16, 8)
+    raise KeyError(tag)
+
+
+BLOCK_TAGS = ["res_encode_c8", "res_pool_c8_16", "res_pool_odd_c3_8", "res_decode_c16_8", "res_encode_c30",
+              "res_encode_c32", "stack3_c8", "convtrans_c16_8", "convtrans_c32_16", "upconcat_c16_8"]
+
+
+@pytest.mark.parametrize("tag", BLOCK_TAGS)
+def test_g3_blocks_fp32(golden_dir, tag):
+    z = _load(golden_dir, "g3_ops.npz")
+    mod = _build(tag)
+    mod.load_state_dict(_sub(z, tag + "/w/"), strict=True)
+    mod = mod.to(DEV).eval()
+    xs = []
+    i = 0
+    while "%s/in%d" % (tag, i) in z.files:
+        x = torch.from_numpy(z["%s/in%d" % (tag, i)]).to(DEV)
+        xs.append(ops.as_input(x, torch.float32).requires_grad_(True))
+        i += 1
+    out = mod(*xs)
+    _close(out, torch.from_numpy(z[tag + "/out"]), 0, 1e-4, tag + " out")
+    out.backward(torch.from_numpy(z[tag + "/gout"]).to(DEV))
+    for i, xi in enumerate(xs):
+        _close(xi.grad, torch.from_numpy(z["%s/gin%d" % (tag, i)]), 1e-3, 1e-6, "%s gin%d" % (tag, i))
+    gref = _sub(z, tag + "/g/")
+    for k, p in mod.named_parameters():
+        if k in gref:
+            assert p.grad is not None, k
+            # conv biases that feed InstanceNorm have an analytically-zero gradient (we write exact zeros,
+            # the reference carries rounding noise); compare on an absolute scale
+            _close(p.grad, gref[k], 1e-3, 2e-5, "%s grad %s" % (tag, k))
+        else:
+            assert p.grad is None, "%s: %s should have no gradient" % (tag, k)
+
+
+@pytest.mark.parametrize("tag,k,stride", [("stem_c1_8", 3, 1), ("stem_c3_32", 3, 1), ("head_c8_3", 1, 1),
+                                          ("head_c32_4", 1, 1), ("skip_k1s2_c8_16", 1, 2)])
+def test_g3_plain_convs_fp32(golden_dir, tag, k, stride):
+    z = _load(golden_dir, "g3_ops.npz")
+    w = torch.from_numpy(z[tag + "/w/weight"]).to(DEV).requires_grad_(True)
+    b = torch.from_numpy(z[tag + "/w/bias"]).to(DEV).requires_grad_(True)
+    x = torch.from_numpy(z[tag + "/in0"]).to(DEV).requires_grad_(True)
+    out = ops.ConvFn.apply(x, w, b, stride, torch.float32, torch.float32)
+    _close(out, torch.from_numpy(z[tag + "/out"]), 0, 1e-4, tag)
+    out.backward(torch.from_numpy(z[tag + "/gout"]).to(DEV))
+    _close(x.grad, torch.from_numpy(z[tag + "/gin0"]), 1e-3, 1e-6, tag + " gin")
+    _close(w.grad, torch.from_numpy(z[tag + "/g/weight"]), 1e-3, 1e-6, tag + " gw")
+    _close(b.grad, torch.from_numpy(z[tag + "/g/bias"]), 1e-3, 1e-6, tag + " gb")
+
+
+# --------------------------------------------------------------------------- losses (G3 / G4)
+def _loss_cases():
+    wc = [1, 1, 2, 2.9]
+    wv = [1.1, 11.6, 205.8, 466.8]
+    return {
+        "hybird_iia": L.HybirdLoss(weight_c=wc, weight_v=wv, alpha=0.9, beta=0.1),
+        "hybird_default": L.HybirdLoss(),
+        "hybird_gamma3": L.HybirdLoss(gamma=3, weight_v=[1, 10, 20, 5]),
+        "diceloss_iia": L.DiceLoss(weight_c=wc, weight_v=wv, alpha=0.9, beta=0.1),
+        "diceloss_default": L.DiceLoss(),
+        "focal_iia": L.FocalLoss(weight_c=wc, weight_v=wv),
+        "focal_default": L.FocalLoss(),
+        "dice_kd": L.Dice(weight_v=[0, 1, 0, 0]),
+        "dice_default": L.Dice(),
+        "dice_tversky": L.Dice(weight_v=wv, alpha=0.3, beta=0.7),
+    }
+
+
+@pytest.mark.parametrize("tag", sorted(_loss_cases()))
+@pytest.mark.parametrize("layout", ["ncdhw", "ndhwc"])
+def test_g3_losses(golden_dir, tag, layout):
+    z = _load(golden_dir, "g3_loss.npz")
+    x = torch.from_numpy(z["x"]).to(DEV)
+    if layout == "ndhwc":
+        x = x.contiguous(memory_format=torch.channels_last_3d)
+    x.requires_grad_(True)
+    y = torch.from_numpy(z["y"].astype(np.int64)).to(DEV)
+    v = _loss_cases()[tag](x, y)
+    assert v.dim() == 0 and v.is_cuda
+    ref = float(z[tag + "/value"])
+    assert abs(v.item() - ref) <= 2e-6 * max(1.0, abs(ref)), (tag, v.item(), ref)
+    v.backward()
+    _close(x.grad, torch.from_numpy(z[tag + "/grad"]), 2e-4, 1e-9, tag + " grad")
+
+
+def test_loss_uint8_labels_legacy_names_and_quirks(golden_dir):
+    z = _load(golden_dir, "g3_loss.npz")
+    x = torch.from_numpy(z["kits/x"]).to(DEV).requires_grad_(True)
+    y8 = torch.from_numpy(z["kits/y"]).to(DEV)
+    v = L.FocalDiceCoefLoss(d_weight=[1, 10, 20])(x, y8)
+    assert abs(v.item() - float(z["kits/value"])) <= 2e-6
+    v.backward()
+    _close(x.grad, torch.from_numpy(z["kits/grad"]), 2e-4, 1e-9, "kits grad")
+    m = L.DiceCoef(weight=[0, 1, 0])(x.detach(), y8.long())
+    ref = O.dice_metric(torch.from_numpy(z["kits/x"]), torch.from_numpy(z["kits/y"].astype(np.int64)),
+                        weight_v=[0, 1, 0])
+    assert abs(m.item() - ref.item()) <= 2e-6
+    # functional dice on device
+    p = torch.from_numpy(z["fdice/p"]).to(DEV)
+    g = torch.from_numpy(z["fdice/g"].astype(np.int64)).to(DEV)
+    assert abs(L.dice(p, g).item() - float(z["fdice/default"])) <= 1e-6
+    assert abs(L.dice(p, g, alpha=0.9, beta=0.1).item() - float(z["fdice/a9b1"])) <= 1e-6
+    # C == 1: labels {0,1} raise like F.one_hot does; all-zero target works
+    x1 = O.synth_image((1, 1, 4, 4, 4), 78).to(DEV)
+    y1 = O.phantom_labels(1, (4, 4, 4), 2).to(DEV)
+    with pytest.raises(RuntimeError):
+        L.HybirdLoss()(x1, y1)
+    import json
+    q = json.load(open(os.path.join(golden_dir, "g4_quirks.json")))
+    assert abs(L.HybirdLoss()(x1, torch.zeros_like(y1)).item() - q["c1_all_zero_target_value"]) <= 2e-6
+    # out-of-range label with C > 1: NaN by default, raises when asked to check
+    xb = O.synth_image((1, 3, 4, 4, 4), 79).to(DEV)
+    yb = torch.full((1, 4, 4, 4), 3, dtype=torch.int64, device=DEV)
+    assert torch.isnan(L.HybirdLoss()(xb, yb))
+    strict = L.HybirdLoss()
+    strict.check_labels = True
+    with pytest.raises(RuntimeError):
+        strict(xb, yb)
+    # weight_c has no effect; absent class weighting
+    xq = O.synth_image((2, 3, 6, 6, 6), 77).to(DEV)
+    yq = O.phantom_labels(2, (6, 6, 6), 3).to(DEV)
+    a = L.HybirdLoss(weight_c=[1, 1, 1], weight_v=[1, 10, 20])(xq, yq).item()
+    b = L.HybirdLoss(weight_c=[5, 0.1, 7], weight_v=[1, 10, 20])(xq, yq).item()
+    assert a == b and abs(a - q["weight_c_ignored_hybird"][0]) <= 2e-6
+    assert abs(L.DiceLoss(weight_v=[0, 0, 1])(xq, yq.clamp(max=1)).item() - q["absent_class_diceloss_w001"]) <= 1e-6
+
+
+# --------------------------------------------------------------------------- whole net (G1 / G2)
+def _g1_model(golden_dir):
+    z = _load(golden_dir, "g1_config1.npz")
+    model = network.ResUnet3D(num_pool=2, num_features=8, in_channels=1, out_channels=2)
+    model.load_state_dict(_sub(z, "w/"), strict=True)
+    return z, model.to(DEV)
+
+
+def test_g1_whole_net_fp32(golden_dir):
+    z, model = _g1_model(golden_dir)
+    model.eval()
+    x = torch.from_numpy(z["x"]).to(DEV)
+    y = torch.from_numpy(z["y"].astype(np.int64)).to(DEV)
+    logits = model(x)
+    assert tuple(logits.shape) == (1, 2, 32, 32, 32) and logits.dtype == torch.float32
+    _close(logits, torch.from_numpy(z["logits"]), 0, 1e-4, "logits")
+    assert torch.equal(logits.argmax(1).to(torch.uint8).cpu(), torch.from_numpy(z["argmax"])), "argmax not bit-exact"
+    for name, fn in (("hybird", L.HybirdLoss()), ("diceloss", L.DiceLoss()), ("focal", L.FocalLoss()),
+                     ("dice", L.Dice())):
+        assert abs(fn(logits, y).item() - float(z["loss/" + name])) <= 5e-6, name
+    L.HybirdLoss()(logits, y).backward()
+    gref = _sub(z, "g/")
+    none_keys = set(z["none_grad_keys"].tolist())
+    for k, p in model.named_parameters():
+        if k in none_keys:
+            assert p.grad is None, k
+        else:
+            _close(p.grad, gref[k], 2e-3, 2e-6, "grad " + k)
+
+
+def test_g1_adam_three_steps(golden_dir):
+    z, model = _g1_model(golden_dir)
+    model.eval()
+    x = torch.from_numpy(z["x"]).to(DEV)
+    y = torch.from_numpy(z["y"].astype(np.int64)).to(DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    losses = []
+    for step in range(3):
+        opt.zero_grad()
+        l = L.HybirdLoss()(model(x), y)
+        l.backward()
+        opt.step()
+        losses.append(l.item())
+    assert np.allclose(losses, z["adam_losses"], rtol=0, atol=2e-5)
+    ref3 = _sub(z, "adam3/")
+    for k, p in model.state_dict().items():
+        d = (p.cpu() - ref3[k]).abs()
+        assert d.max().item() <= 2.1e-4 * 3, k          # Adam moves ~0-gradient elements by +-lr on noise
+        if not k.endswith(("conv1.bias", "conv2.bias", "up.0.bias")):
+            assert (d > 1e-5).float().mean().item() <= 0.02, k
+
+
+def test_g2_dropout_with_injected_masks(golden_dir):
+    z1, model = _g1_model(golden_dir)
+    z = _load(golden_dir, "g2_dropout.npz")
+    model.train()
+    masks = _sub(z, "mask/")
+    mods = dict(model.named_modules())
+    for name, keep in masks.items():
+        mods[name[: -len(".dropout")]]._forced_keep = keep
+    x = torch.from_numpy(z1["x"]).to(DEV)
+    y = torch.from_numpy(z1["y"].astype(np.int64)).to(DEV)
+    logits = model(x)
+    _close(logits, torch.from_numpy(z["logits"]), 0, 2e-4, "train-mode logits")
+    l = L.HybirdLoss()(logits, y)
+    assert abs(l.item() - float(z["loss"])) <= 1e-5
+    l.backward()
+    for k, ref in _sub(z, "g/").items():
+        _close(dict(model.named_parameters())[k].grad, ref, 3e-3, 2e-6, "dropout grad " + k)
+
+
+def test_train_mode_dropout_statistics():
+    torch.manual_seed(3)
+    blk = network.ResBlock(16, 16).to(DEV).train()
+    x = ops.as_input(O.synth_image((4, 16, 8, 8, 8), 5).to(DEV), torch.float32)
+    scale = blk._drop_scale(x)
+    assert scale.shape == (64,)
+    vals = set(scale.cpu().tolist())
+    assert vals <= {0.0, 2.0} and len(vals) == 2
+    out = blk(x)
+    assert torch.isfinite(out).all()
+
+
+# --------------------------------------------------------------------------- bf16 mode
+def test_g1_whole_net_bf16(golden_dir):
+    """bf16 storage / fp32 accumulate.  Tolerance: logits within 0.08 abs of the fp32 reference (bf16 has
+    8 bits of mantissa and InstanceNorm re-normalises after every conv); argmax may flip only where the
+    reference's top-2 margin is below 0.1; loss within 2e-2; weight gradients within 8 % of max."""
+    z, model = _g1_model(golden_dir)
+    network.set_compute_dtype(model, torch.bfloat16)
+    model.eval()
+    x = torch.from_numpy(z["x"]).to(DEV)
+    y = torch.from_numpy(z["y"].astype(np.int64)).to(DEV)
+    logits = model(x)
+    assert logits.dtype == torch.float32
+    ref = torch.from_numpy(z["logits"])
+    got = logits.detach().cpu()
+    assert (got - ref).abs().max().item() <= 0.08
+    margin = (ref[:, 0] - ref[:, 1]).abs()
+    flips = got.argmax(1) != ref.argmax(1)
+    assert not (flips & (margin > 0.1)).any()
+    assert flips.float().mean().item() < 0.02
+    l = L.HybirdLoss()(logits, y)
+    assert abs(l.item() - float(z["loss/hybird"])) <= 2e-2
+    l.backward()
+    gref = _sub(z, "g/")
+    for k, p in model.named_parameters():
+        if k in gref and k.endswith("weight"):
+            _close(p.grad, gref[k], 0.08, 1e-6, "bf16 grad " + k)
+
+
+# --------------------------------------------------------------------------- C ABI directly: pitches, odd sizes
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_with_channel_pitch_and_odd_extents(dtype):
+    """x is a channel slice of a wider NDHWC buffer (ld > c), extents are odd, stride 2."""
+    g = torch.Generator().manual_seed(11)
+    xw = torch.randn(2, 24, 5, 7, 9, generator=g)
+    w = torch.randn(16, 8, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(16, generator=g)
+    wide = ops.as_input(xw.to(DEV), dtype)
+    x = wide[:, 8:16]
+    assert N.desc(x).ld == 24
+    pw = ops.pack_weight(w.to(DEV), N.ROLE_CONV_FWD, dtype)
+    y = ops.conv_fwd(x, pw, b.to(DEV), 16, 3, 2)
+    xr = xw[:, 8:16].to(dtype).float()
+    ref = torch.nn.functional.conv3d(xr, w.to(dtype).float(), b, stride=2, padding=1)
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    _close(y, ref, tol, tol, "conv pitch")
+    # dgrad + wgrad of the same conv
+    gy = torch.randn(ref.shape, generator=g)
+    gyd = ops.as_input(gy.to(DEV), dtype)
+    pwd = ops.pack_weight(w.to(DEV), N.ROLE_CONV_DGRAD, dtype)
+    gx = ops.conv_dgrad(gyd, pwd, tuple(x.shape), 3, 2)
+    gw = ops.conv_wgrad(x, gyd, 3, 2)
+    xr.requires_grad_(True)
+    wr = w.to(dtype).float().requires_grad_(True)
+    torch.nn.functional.conv3d(xr, wr, b, stride=2, padding=1).backward(gy.to(dtype).float())
+    _close(gx, xr.grad, tol, tol, "dgrad pitch")
+    _close(gw, wr.grad, tol, tol * 10, "wgrad pitch")
+
+
+def test_norm_kernels_vs_oracle_bf16_and_fp32():
+    g = torch.Generator().manual_seed(12)
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+        for c in (1, 3, 8, 30, 32, 320):
+            yv = torch.randn(2, c, 4, 5, 6, generator=g) * 2 + 0.5
+            rv = torch.randn(2, c, 4, 5, 6, generator=g)
+            y = ops.as_input(yv.to(DEV), dtype)
+            r = ops.as_input(rv.to(DEV), dtype)
+            mean, scale = ops.in_stats(y)
+            out = ops.in_lrelu_fwd(y, mean, scale, res=r)
+            yf = y.float().cpu()
+            ref = O.lrelu(O.instance_norm(yf) + r.float().cpu())
+            _close(out, ref, tol, tol, "in_lrelu c=%d" % c)
+            _close(mean.view(2, c), yf.mean(dim=(2, 3, 4)), 1e-5, 1e-5, "mean")
+            s = ops.channel_sum(y)
+            _close(s, yf.sum(dim=(0, 2, 3, 4)), 1e-4, 1e-3, "channel_sum")
+
+
+def test_layout_repack_roundtrip():
+    x = O.synth_image((2, 5, 3, 4, 7), 9).to(DEV)
+    for dtype in (torch.float32, torch.bfloat16):
+        cl = ops.ncdhw_to_ndhwc(x, dtype)
+        assert N.is_ndhwc(cl) and cl.dtype == dtype
+        back = ops.ndhwc_to_ncdhw(cl)
+        assert torch.equal(back, x.to(dtype).float())
+        assert torch.equal(cl.float(), x.to(dtype).float())
+
+
+def test_api_rejects_bad_shapes():
+    x = N.new_act(1, 8, 4, 4, 4, torch.float32, DEV)
+    y = N.new_act(1, 8, 5, 4, 4, torch.float32, DEV)   # wrong extent
+    pw = ops.pack_weight(torch.zeros(8, 8, 3, 3, 3, device=DEV), N.ROLE_CONV_FWD, torch.float32)
+    dx, dy = N.desc(x), N.desc(y)
+    rc = N.lib.ru3d_conv3d_fwd(N.ref(dx), N.ptr(pw), None, None, N.ref(dy), 3, 1, N.F32, N.F32, N.stream())
+    assert rc < 0 and b"extents" in N.lib.ru3d_last_error()
+    with pytest.raises(N.Ru3dError):
+        ops.conv_fwd(torch.zeros(1, 8, 4, 4, 4), pw, None, 8, 3, 1)   # CPU tensor: no fallback
