@@ -46,6 +46,39 @@ def _conv_out(size, k, s):
     return (size + 2 * (k // 2) - k) // s + 1
 
 
+class Probe:
+    """bench.py: times every launch of ONE conv kernel shape with HIP events recorded on the launch stream
+    (torch's current stream is the stream the C ABI is handed)."""
+
+    def __init__(self, cin, cout, k, stride, extent):
+        self.key = (cin, cout, k, stride, tuple(extent))
+        self.pairs = []
+
+    def match(self, cin, cout, k, stride, extent):
+        return (cin, cout, k, stride, tuple(extent)) == self.key
+
+    def begin(self):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.pairs.append((e0, e1))
+        return e1
+
+    def result(self):
+        torch.cuda.synchronize()
+        if not self.pairs:
+            return 0, 0.0
+        total = sum(a.elapsed_time(b) for a, b in self.pairs)
+        return len(self.pairs), total / len(self.pairs)
+
+
+_PROBE = [None]
+
+
+def set_probe(p):
+    _PROBE[0] = p
+
+
 def conv_fwd(x, pw, bias, cout, k, stride, res=None, out_dtype=None):
     n, _, d, h, w = x.shape
     out_dtype = out_dtype or x.dtype
@@ -54,8 +87,12 @@ def conv_fwd(x, pw, bias, cout, k, stride, res=None, out_dtype=None):
     b = _bias(bias)
     dx, dyy = desc(x), desc(y)
     dr = desc(res) if res is not None else None
+    p = _PROBE[0]
+    end = p.begin() if (p is not None and p.match(x.shape[1], cout, k, stride, x.shape[2:])) else None
     check(N.lib.ru3d_conv3d_fwd(ref(dx), ptr(pw), ptr(b), ref(dr), ref(dyy), k, stride, N.dtype_code(x.dtype),
                                 N.dtype_code(out_dtype), stream()), "conv3d_fwd")
+    if end is not None:
+        end.record()
     return y
 
 
@@ -64,8 +101,13 @@ def conv_dgrad(dy, pw, in_shape, k, stride, res=None):
     dx = N.new_act(n, cin, d, h, w, dy.dtype, dy.device)
     ddy, ddx = desc(dy), desc(dx)
     dr = desc(res) if res is not None else None
+    p = _PROBE[0]
+    # the stride-1 input gradient runs the same gather kernel as the forward (taps reversed)
+    end = p.begin() if (p is not None and stride == 1 and p.match(dy.shape[1], cin, k, 1, dy.shape[2:])) else None
     check(N.lib.ru3d_conv3d_dgrad(ref(ddy), ptr(pw), ref(dr), ref(ddx), k, stride, N.dtype_code(dy.dtype), stream()),
           "conv3d_dgrad")
+    if end is not None:
+        end.record()
     return dx
 
 

@@ -37,6 +37,39 @@ IN_EPS = 1e-5        # nn.InstanceNorm3d default (network.py:384)
 DROP_P = 0.5         # nn.Dropout3d(p=0.5) (network.py:383)
 
 
+# --------------------------------------------------------------------------- storage-precision model
+class _Store(torch.autograd.Function):
+    """Models a tensor that is STORED in a narrower dtype between kernels (bf16 mode of the HIP path):
+    the forward value and the gradient flowing back through the same point are both rounded."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype = dtype
+        return x.to(dtype).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
+_STORAGE = [None]   # None = exact (fp32/fp64) pipeline
+
+
+def set_storage(dtype):
+    """oracle.set_storage(torch.bfloat16) makes every inter-kernel tensor (and every weight as the kernels
+    read it) round-trip through bf16, with fp32+ accumulation inside each op - a statistical model of the
+    bf16 mode, used to bound its error; set_storage(None) restores the exact pipeline."""
+    _STORAGE[0] = dtype
+
+
+def _st(x):
+    return x if _STORAGE[0] is None else _Store.apply(x, _STORAGE[0])
+
+
+def _wq(w):
+    return w if _STORAGE[0] is None else _Store.apply(w, _STORAGE[0])
+
+
 # --------------------------------------------------------------------------- model
 def paired_features(num_pool, num_features):
     """network.py:135-141."""
@@ -69,14 +102,14 @@ def res_block(x, w, prefix, stride=1, keep=None):
     w2, b2 = w[prefix + "conv2.weight"], w[prefix + "conv2.bias"]
     cin, cout = w1.shape[1], w1.shape[0]
     if cin != cout or stride != 1:
-        skip = F.conv3d(x, w[prefix + "skip_conv.weight"], w[prefix + "skip_conv.bias"], stride=stride)
+        skip = _st(F.conv3d(x, _wq(w[prefix + "skip_conv.weight"]), w[prefix + "skip_conv.bias"], stride=stride))
     else:
         skip = x
-    y = F.conv3d(x, w1, b1, stride=stride, padding=1)
+    y = _st(F.conv3d(x, _wq(w1), b1, stride=stride, padding=1))
     scale = None if keep is None else keep.to(y.dtype) / (1.0 - DROP_P)
-    y = lrelu(instance_norm(y, scale))
-    y = F.conv3d(y, w2, b2, padding=1)
-    return lrelu(instance_norm(y) + skip)
+    y = _st(lrelu(instance_norm(y, scale)))
+    y = _st(F.conv3d(y, _wq(w2), b2, padding=1))
+    return _st(lrelu(instance_norm(y) + skip))
 
 
 def res_stack(x, w, prefix, num_stacks, stride=1, keeps=None):
@@ -89,9 +122,9 @@ def res_stack(x, w, prefix, num_stacks, stride=1, keeps=None):
 
 def conv_trans(x, w, prefix):
     """network.py:311-317: ConvTranspose3d(k3,s2,p1) -> ConstantPad3d((0,1,0,1,0,1)) -> IN -> LeakyReLU."""
-    y = F.conv_transpose3d(x, w[prefix + "up.0.weight"], w[prefix + "up.0.bias"], stride=2, padding=1)
-    y = F.pad(y, (0, 1, 0, 1, 0, 1), value=0.0)
-    return lrelu(instance_norm(y))
+    y = F.conv_transpose3d(x, _wq(w[prefix + "up.0.weight"]), w[prefix + "up.0.bias"], stride=2, padding=1)
+    y = _st(F.pad(y, (0, 1, 0, 1, 0, 1), value=0.0))
+    return _st(lrelu(instance_norm(y)))
 
 
 def up_concat(x, skip, w, prefix):
@@ -108,7 +141,7 @@ def unet_forward(x, w, num_pool, keeps=None, prefix="net."):
     def k(name):
         return None if keeps is None else keeps.get(name)
 
-    x = F.conv3d(x, w[prefix + "conv.weight"], w[prefix + "conv.bias"], padding=1)
+    x = _st(F.conv3d(_st(x), _wq(w[prefix + "conv.weight"]), w[prefix + "conv.bias"], padding=1))
     skips = []
     for i in range(num_pool):
         x = res_stack(x, w, prefix + "encode_blocks.%d." % i, max(i, 1), 1, keeps)
@@ -118,7 +151,7 @@ def unet_forward(x, w, num_pool, keeps=None, prefix="net."):
     for i in range(num_pool - 1, -1, -1):
         x = up_concat(x, skips[i], w, prefix + "up_blocks.%d." % i)
         x = res_block(x, w, prefix + "decode_blocks.%d." % i, 1, k(prefix + "decode_blocks.%d.dropout" % i))
-    return F.conv3d(x, w[prefix + "fc.weight"], w[prefix + "fc.bias"])
+    return F.conv3d(x, _wq(w[prefix + "fc.weight"]), w[prefix + "fc.bias"])   # logits stay fp32
 
 
 def init_state_dict(num_pool, num_features, in_channels, out_channels, seed=0):

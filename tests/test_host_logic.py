@@ -1,0 +1,219 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/ru3d.h declares (no
+compute calls - there is no GPU here), the drop-in modules keep the reference's import surface,
+state_dict contract and Trainer semantics, and the native path refuses CPU tensors loudly."""
+import ctypes
+import json
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import _native as N
+import loss as L
+import network
+import trainer as T
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "ru3d.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(ru3d_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _header_functions()
+    assert len(declared) >= 28
+    assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
+    raw = ctypes.CDLL(N.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert N.lib.ru3d_version() == 100
+    # pure host-side queries work without a device
+    assert N.lib.ru3d_loss_state_bytes(3) > 0
+    assert N.lib.ru3d_packed_weight_bytes(32, 32, 3, N.ROLE_CONV_FWD, N.BF16) > 0
+    assert N.lib.ru3d_packed_weight_bytes(32, 32, 5, N.ROLE_CONV_FWD, N.BF16) == 0   # k=5 unsupported
+    # argument validation happens before any launch
+    rc = N.lib.ru3d_conv3d_fwd(None, None, None, None, None, 3, 1, N.F32, N.F32, None)
+    assert rc < 0 and b"conv3d_fwd" in N.lib.ru3d_last_error()
+
+
+def test_ndhwc_descriptor_logic():
+    t = N.new_act(2, 6, 3, 4, 5, torch.float32, "cpu")
+    assert tuple(t.shape) == (2, 6, 3, 4, 5) and N.is_ndhwc(t)
+    assert t.is_contiguous(memory_format=torch.channels_last_3d)
+    sl = t[:, 2:4]
+    assert N.is_ndhwc(sl)
+    assert not N.is_ndhwc(torch.zeros(2, 6, 3, 4, 5))
+    assert N.is_ndhwc(torch.zeros(2, 1, 3, 4, 5))              # C == 1: NCDHW is NDHWC
+    assert not N.is_ndhwc(torch.zeros(2, 6, 3, 4))
+    with pytest.raises(N.Ru3dError):
+        N.desc(t)                                               # CPU tensor: refused
+    assert N.dtype_code(torch.bfloat16) == N.BF16
+    with pytest.raises(N.Ru3dError):
+        N.dtype_code(torch.float16)
+
+
+def test_state_dict_contract_and_init_parity(golden_dir):
+    info = json.load(open(os.path.join(golden_dir, "g5_checkpoint.json")))
+    torch.manual_seed(0)
+    model = network.ResUnet3D(num_pool=2, num_features=8, in_channels=1, out_channels=2)
+    sd = model.state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == info["model_state_dict"]
+    assert list(sd.keys()) == list(info["model_state_dict"].keys())            # same order too
+    # same construction order => same default initialisation as the reference under the same seed
+    z = np.load(os.path.join(golden_dir, "g1_config1.npz"))
+    for k, v in sd.items():
+        assert np.array_equal(v.numpy(), z["w/" + k]), k
+    model.load_state_dict({k: torch.from_numpy(z["adam3/" + k]) for k in sd}, strict=True)
+    m = network.ResUnet3D()
+    assert (m.num_pool, m.num_features, m.in_channels, m.out_channels) == (4, 30, 1, 1)
+    assert sum(p.numel() for p in network.ResUnet3D(4, 32, 1, 3).parameters()) == info["config2_num_parameters"]
+
+
+def test_import_surface_matches_reference_scripts():
+    for name in ("ResUnet3D", "ResAttrUnet3D", "ResAttrUnet3D2", "ResAttrBNUnet3D", "generate_paired_features",
+                 "generate_paired_features2", "Unet", "ResBlock", "ResBlockStack", "ConvBlock", "ConvBlockStack",
+                 "RecBlock", "ResRecBlock", "ConvTrans3D", "UpConcat", "AttBlock", "MaxPoolBlock", "none_fn"):
+        assert hasattr(network, name), name
+    for name in ("logits", "flatten_and_tranpose_C", "dice", "focal_loss", "Dice", "DiceLoss", "FocalLoss",
+                 "HybirdLoss", "DiceCoef", "FocalDiceCoefLoss"):
+        assert hasattr(L, name), name
+    assert network.generate_paired_features(2, 8) == [[8, 8], [16, 16], [32, 32], [16, 16], [8, 8]]
+    assert network.generate_paired_features2(2, 8) == [[8, 16], [16, 32], [32, 32], [16, 16], [8, 8]]
+    # run_train.py constructs the net through the assembler with block classes as arguments
+    net = network.Unet(in_channels=1, out_channels=3, paired_features=network.generate_paired_features(2, 4),
+                       pool_block=network.ResBlock, pool_kwargs={'stride': 2}, up_kwargs={'attention': True},
+                       encode_block=network.ResBlockStack, encode_kwargs_fn=lambda lv: {'num_stacks': max(lv, 1)},
+                       decode_block=network.ResBlock)
+    assert hasattr(net.up_blocks[0], "att_gate")
+    # attention / BatchNorm variants exist and are wired as torch modules
+    bn = network.ResAttrBNUnet3D(num_pool=1, num_features=4)
+    assert isinstance(bn.net.pool_blocks[0].norm, torch.nn.BatchNorm3d) and not bn.net.pool_blocks[0]._native
+    assert network.ResBlock(4, 4)._native and network.ConvTrans3D(8, 4)._native
+
+
+def test_native_blocks_refuse_cpu_tensors():
+    model = network.ResUnet3D(num_pool=1, num_features=4, in_channels=1, out_channels=2)
+    with pytest.raises(N.Ru3dError, match="no CPU fallback"):
+        model(torch.zeros(1, 1, 8, 8, 8))
+    with pytest.raises(N.Ru3dError):
+        network.ResBlock(4, 4)(torch.zeros(1, 4, 4, 4, 4))
+    with pytest.raises(N.Ru3dError):
+        L.HybirdLoss()(torch.zeros(1, 2, 4, 4, 4), torch.zeros(1, 4, 4, 4, dtype=torch.long))
+    # host-side functional dice (evaluate_case path) is plain host code
+    p = torch.tensor([1.0, 0.0, 1.0, 1.0])
+    g = torch.tensor([1, 0, 0, 1])
+    assert abs(L.dice(p, g).item() - (2 + 1e-7) / (2 + 0.5 * 0 + 0.5 * 1 + 1e-7)) < 1e-6
+    assert torch.allclose(L.logits(torch.zeros(1, 2, 3)), torch.full((1, 2, 3), 0.5))
+
+
+def test_non_native_variants_run_on_cpu_as_torch_modules():
+    blk = network.ConvBlockStack(2, 4, num_stacks=2)
+    out = blk(torch.randn(1, 2, 6, 6, 6))
+    assert tuple(out.shape) == (1, 4, 6, 6, 6)
+    att = network.AttBlock(4)
+    assert tuple(att(torch.randn(1, 4, 4, 4, 4), torch.randn(1, 4, 4, 4, 4)).shape) == (1, 4, 4, 4, 4)
+    rr = network.ResRecBlock(2, 4, dropout_op=None)
+    assert tuple(rr(torch.randn(1, 2, 4, 4, 4)).shape) == (1, 4, 4, 4, 4)
+
+
+# --------------------------------------------------------------------------- Trainer plumbing (toy torch model on CPU)
+class _ToyData(torch.utils.data.Dataset):
+    def __init__(self, n=8, nan_at=None):
+        g = torch.Generator().manual_seed(0)
+        self.x = torch.randn(n, 1, 4, 4, 4, generator=g)
+        self.y = (self.x[:, 0] > 0).long()
+        self.nan_at = nan_at
+
+    def __len__(self):
+        return len(self.x)
+
+    def __getitem__(self, i):
+        x = self.x[i].clone()
+        if self.nan_at == i:
+            x[:] = float("nan")
+        return {"image": x, "label": self.y[i], "case_id": "c%d" % i, "affine": np.eye(4)}
+
+
+class _ToyLoss(torch.nn.Module):
+    def forward(self, pred, target):
+        return torch.nn.functional.cross_entropy(pred, target)
+
+
+def _toy_trainer(tmp_path, **kw):
+    model = torch.nn.Conv3d(1, 2, 1)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    sch = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.2, patience=25)
+    np.random.seed(0)
+    tr = T.Trainer(model=model, optimizer=opt, loss=_ToyLoss(), dataset=kw.pop("dataset", _ToyData()), batch_size=2,
+                   dataloader_kwargs={"num_workers": 0}, scheduler=sch, progress=False,
+                   metrics={"acc": lambda p, t: (p.argmax(1) == t).float().mean()}, **kw)
+    return tr
+
+
+def test_trainer_fit_checkpoint_resume(tmp_path):
+    tr = _toy_trainer(tmp_path, valid_split=0.25, num_samples=6)
+    assert len(tr.valid_indices) == 2 and len(tr.train_indices) == 6
+    save = str(tmp_path / "run")
+    best = tr.fit(num_epochs=2, save_dir=save)
+    assert set(best) == {"loss", "acc"} and math.isfinite(best["loss"])
+    ckpt = torch.load(save + "-last.pt", weights_only=False)
+    assert set(ckpt) == {"model_state_dict", "optimizer_state_dict", "current_epoch", "train_indices",
+                         "valid_indices", "best_result", "scheduler_state_dict"}
+    assert ckpt["current_epoch"] == 1 and os.path.exists(save + "-best.pt")
+    tr2 = _toy_trainer(tmp_path, valid_split=0.25, num_samples=6)
+    tr2.load_checkpoint(save + "-last.pt")
+    assert tr2.current_epoch == 2 and tr2.train_indices == ckpt["train_indices"]
+    tr2.fit(num_epochs=3)
+    assert tr2.current_epoch == 2          # ran exactly epoch index 2
+    assert tr.get_lr() == 1e-2
+    tr.set_lr(5e-3)
+    assert tr.get_lr() == 5e-3
+    assert "parameters" in tr.summary((1, 4, 4, 4))
+
+
+def test_trainer_nan_step_is_skipped_but_applied(tmp_path):
+    # reference trainer.py:496 vs 505-506: the optimizer step happens before the NaN test
+    tr = _toy_trainer(tmp_path, dataset=_ToyData(4, nan_at=1), valid_split=0.0)
+    tr.dataloader_kwargs["batch_size"] = 1
+    tr.num_epochs = 1
+    loader = tr._loader(list(range(4)), None, None, False)
+    res = tr.batch_loop(loader, is_train=True)
+    assert math.isfinite(res["loss"])          # NaN step excluded from the mean
+    assert any(torch.isnan(p).any() for p in tr.model.parameters())   # ... but its update was applied
+
+
+def test_trainer_legacy_spelling(tmp_path):
+    model = torch.nn.Conv3d(1, 2, 1)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    tr = T.Trainer(model=model, optimizer=opt, criterion=_ToyLoss(), tr_transform=None, vd_transform=None,
+                   progress=False)
+    assert tr.loss is not None and tr.dataset is None
+    log = str(tmp_path / "legacy")
+    tr.fit(_ToyData(), batch_size=2, epochs=1, num_samples=4, log_dir=log, save_dir=log, save_last=True,
+           save_best=False, num_workers=0, pin_memory=False)
+    assert os.path.exists(log + "-last.pt") and not os.path.exists(log + "-best.pt")
+    tr.save(str(tmp_path / "init.pt"))
+    tr.load(str(tmp_path / "init.pt"))
+    with pytest.raises(TypeError):
+        T.Trainer(model=model, optimizer=opt)
+
+
+def test_deferred_sync_gives_same_means(tmp_path):
+    torch.manual_seed(0)
+    a = _toy_trainer(tmp_path, valid_split=0.0)
+    torch.manual_seed(0)
+    b = _toy_trainer(tmp_path, valid_split=0.0, sync_every=4)
+    b.model.load_state_dict(a.model.state_dict())
+    for t in (a, b):
+        t.num_epochs = 1
+    la = a._loader(list(range(8)), None, None, False)
+    lb = b._loader(list(range(8)), None, None, False)
+    ra, rb = a.batch_loop(la), b.batch_loop(lb)
+    assert ra.keys() == rb.keys() and abs(ra["loss"] - rb["loss"]) < 1e-6
