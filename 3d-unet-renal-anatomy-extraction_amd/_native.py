@@ -33,8 +33,8 @@ _vp, _i, _i64, _f, _sz, _u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, c
 SIGNATURES = {
     "ru3d_version": (_i, []),
     "ru3d_last_error": (ctypes.c_char_p, []),
-    "ru3d_packed_weight_bytes": (_sz, [_i, _i, _i, _i, _i]),
-    "ru3d_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ru3d_packed_weight_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "ru3d_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ru3d_conv3d_fwd": (_i, [_P, _vp, _vp, _P, _P, _i, _i, _i, _i, _vp]),
     "ru3d_conv3d_dgrad": (_i, [_P, _vp, _P, _P, _i, _i, _i, _vp]),
     "ru3d_conv3d_wgrad_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),

@@ -15,7 +15,7 @@ IN_EPS = 1e-5        # nn.InstanceNorm3d default eps (reference network.py:384)
 
 
 # --------------------------------------------------------------------------- thin wrappers
-def pack_weight(w, role, dtype):
+def pack_weight(w, role, dtype, stride=1):
     """w: fp32 parameter in the reference layout (Conv3d [Cout,Cin,k,k,k]; ConvTranspose3d [Cin,Cout,k,k,k])."""
     N.require_device(w, "weight")
     w = w.detach()
@@ -27,11 +27,13 @@ def pack_weight(w, role, dtype):
     else:
         cout, cin = w.shape[0], w.shape[1]
     code = N.dtype_code(dtype)
-    nbytes = N.lib.ru3d_packed_weight_bytes(cout, cin, k, role, code)
+    if role in (N.ROLE_CONVT_FWD, N.ROLE_CONVT_DGRAD):
+        stride = 2
+    nbytes = N.lib.ru3d_packed_weight_bytes(cout, cin, k, stride, role, code)
     if nbytes == 0:
         raise N.Ru3dError("ru3d: cannot pack weight of shape %s" % (tuple(w.shape),))
     out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-    check(N.lib.ru3d_pack_weight(ptr(w), ptr(out), cout, cin, k, role, code, stream()), "pack_weight")
+    check(N.lib.ru3d_pack_weight(ptr(w), ptr(out), cout, cin, k, stride, role, code, stream()), "pack_weight")
     return out
 
 
@@ -291,7 +293,7 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, storage_dtype, out_dtype):
         xin = as_input(x, storage_dtype)
         k = weight.shape[2]
-        pw = pack_weight(weight, N.ROLE_CONV_FWD, storage_dtype)
+        pw = pack_weight(weight, N.ROLE_CONV_FWD, storage_dtype, stride)
         y = conv_fwd(xin, pw, bias, weight.shape[0], k, stride, out_dtype=out_dtype)
         ctx.save_for_backward(xin, weight)
         ctx.stride, ctx.k, ctx.has_bias = stride, k, bias is not None
@@ -310,7 +312,7 @@ class ConvFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = channel_sum(gy)
         if ctx.needs_input_grad[0]:
-            pwd = pack_weight(weight, N.ROLE_CONV_DGRAD, sd)
+            pwd = pack_weight(weight, N.ROLE_CONV_DGRAD, sd, ctx.stride)
             gx = conv_dgrad(gy, pwd, tuple(xin.shape), ctx.k, ctx.stride)
             if gx.dtype != ctx.in_dtype:
                 gx = gx.to(ctx.in_dtype)
@@ -329,7 +331,7 @@ class ResBlockFn(torch.autograd.Function):
         sd = x.dtype
         x = N.to_ndhwc(x)
         cout = w1.shape[0]
-        pw1 = pack_weight(w1, N.ROLE_CONV_FWD, sd)
+        pw1 = pack_weight(w1, N.ROLE_CONV_FWD, sd, stride)
         y1 = conv_fwd(x, pw1, b1, cout, 3, stride)
         mean1, scale1 = in_stats(y1, drop_scale)
         a1 = in_lrelu_fwd(y1, mean1, scale1)
@@ -337,7 +339,7 @@ class ResBlockFn(torch.autograd.Function):
         y2 = conv_fwd(a1, pw2, b2, cout, 3, 1)
         mean2, scale2 = in_stats(y2)
         if ws is not None:
-            pws = pack_weight(ws, N.ROLE_CONV_FWD, sd)
+            pws = pack_weight(ws, N.ROLE_CONV_FWD, sd, stride)
             skip = conv_fwd(x, pws, bs, cout, 1, stride)
         else:
             skip = x
@@ -369,12 +371,12 @@ class ResBlockFn(torch.autograd.Function):
             gws = conv_wgrad(x, gpre, 1, stride)
             gbs = channel_sum(gpre)
             if need_gx:
-                pwsd = pack_weight(ws, N.ROLE_CONV_DGRAD, sd)
+                pwsd = pack_weight(ws, N.ROLE_CONV_DGRAD, sd, stride)
                 gx0 = conv_dgrad(gpre, pwsd, tuple(x.shape), 1, stride)
-                pw1d = pack_weight(w1, N.ROLE_CONV_DGRAD, sd)
+                pw1d = pack_weight(w1, N.ROLE_CONV_DGRAD, sd, stride)
                 gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gx0)
         elif need_gx:
-            pw1d = pack_weight(w1, N.ROLE_CONV_DGRAD, sd)
+            pw1d = pack_weight(w1, N.ROLE_CONV_DGRAD, sd, stride)
             gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gpre)
         return gx, gw1, gb1, gw2, gb2, gws, gbs, None, None
 

@@ -47,26 +47,35 @@ static void role_channels(int cout, int cin, int role, int* kin, int* kout, int6
     }
 }
 
-extern "C" size_t ru3d_packed_weight_bytes(int cout, int cin, int k, int role, int dtype) {
-    if (cout <= 0 || cin <= 0 || (k != 1 && k != 3) || role < 0 || role > 3 || !dtype_ok(dtype)) return 0;
+// does the kernel that will consume this packed weight run on the MFMA path?  (gather form, k3, stride 1)
+static bool role_uses_mfma(int kin, int kout, int k, int stride, int role, int dtype) {
+    const bool gather_s1 = (role == RU3D_ROLE_CONV_FWD || role == RU3D_ROLE_CONV_DGRAD) && stride == 1;
+    return gather_s1 && mfma_conv_eligible(kin, kout, k, dtype, dtype);
+}
+
+extern "C" size_t ru3d_packed_weight_bytes(int cout, int cin, int k, int stride, int role, int dtype) {
+    if (cout <= 0 || cin <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2) || role < 0 || role > 3 ||
+        !dtype_ok(dtype))
+        return 0;
     const int taps = k * k * k;
     int kin, kout;
     int64_t s_o, s_i;
     role_channels(cout, cin, role, &kin, &kout, &s_o, &s_i, taps);
-    if (mfma_conv_eligible(kin, kout, k, dtype, dtype)) return mfma_packed_bytes(kin, kout, taps);
+    if (role_uses_mfma(kin, kout, k, stride, role, dtype)) return mfma_packed_bytes(kin, kout, taps);
     return (size_t)taps * kin * generic_cout_pad(kout) * (dtype == RU3D_F32 ? 4 : 2);
 }
 
-extern "C" int ru3d_pack_weight(const float* src, void* dst, int cout, int cin, int k, int role, int dtype,
+extern "C" int ru3d_pack_weight(const float* src, void* dst, int cout, int cin, int k, int stride, int role, int dtype,
                                 void* stream) {
     RU3D_REQUIRE(src && dst, "pack_weight: null pointer");
-    RU3D_REQUIRE(cout > 0 && cin > 0 && (k == 1 || k == 3), "pack_weight: bad shape cout=%d cin=%d k=%d", cout, cin, k);
+    RU3D_REQUIRE(cout > 0 && cin > 0 && (k == 1 || k == 3) && (stride == 1 || stride == 2),
+                 "pack_weight: bad shape cout=%d cin=%d k=%d stride=%d", cout, cin, k, stride);
     RU3D_REQUIRE(role >= 0 && role <= 3 && dtype_ok(dtype), "pack_weight: bad role/dtype");
     const int taps = k * k * k;
     int kin, kout;
     int64_t s_o, s_i;
     role_channels(cout, cin, role, &kin, &kout, &s_o, &s_i, taps);
-    if (mfma_conv_eligible(kin, kout, k, dtype, dtype))
+    if (role_uses_mfma(kin, kout, k, stride, role, dtype))
         return pack_mfma_launch(src, dst, kin, kout, taps, s_o, s_i, 0, as_stream(stream));
     return pack_generic_launch(src, dst, kin, kout, taps, s_o, s_i, 0, dtype, as_stream(stream));
 }
@@ -82,7 +91,7 @@ static int run_conv(const ru3d_tensor* x, const void* w, const float* bias, cons
     g.ldr = res ? res->ld : 0;
     g.k = k; g.stride = stride; g.pad = k / 2;
     g.transposed = transposed; g.zero_far = zero_far; g.flip = flip;
-    if (mfma_conv_eligible(g.Cin, g.Cout, k, dtype, y_dtype))
+    if (mfma_conv_eligible(g.Cin, g.Cout, k, dtype, y_dtype) && mfma_conv_geometry_ok(g))
         return conv_mfma_launch(x->ptr, w, bias, res ? res->ptr : nullptr, y->ptr, g, st);
     return conv_generic_launch(x->ptr, w, bias, res ? res->ptr : nullptr, y->ptr, g, dtype, y_dtype, st);
 }

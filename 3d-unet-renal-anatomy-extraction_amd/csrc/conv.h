@@ -36,6 +36,7 @@ int wgrad_generic_launch(const void* x, const void* dy, float* dw, void* ws, siz
 
 // conv_mfma.hip (bf16 MFMA implicit GEMM)
 bool mfma_conv_eligible(int cin, int cout, int k, int dtype, int y_dtype);
+bool mfma_conv_geometry_ok(const ConvGeom& g);
 size_t mfma_packed_bytes(int cin, int cout, int taps);
 int pack_mfma_launch(const float* src, void* dst, int cin, int cout, int taps, int64_t s_o, int64_t s_i, int flip,
                      hipStream_t st);

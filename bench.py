@@ -58,6 +58,7 @@ def cpu_baseline(args):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, int(os.environ.get("RU3D_CPU_THREADS", "16")))   # the GPU box's CPU share per GPU
     torch.set_num_threads(cores)
     patch = args.patch if args.patch <= 128 else 128
     w = O.init_state_dict(args.pools, args.features, 1, args.classes, seed=0)

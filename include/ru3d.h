@@ -68,10 +68,11 @@ const char* ru3d_last_error(void);
 
 /* ------------------------------------------------------------------ weights ----------------- */
 /* Number of bytes of the packed form of a weight (layout is private to the library and depends on
- * (cin, cout, k, dtype, role)). */
-size_t ru3d_packed_weight_bytes(int cout, int cin, int k, int role, int dtype);
+ * (cin, cout, k, stride, dtype, role); `stride` is the nn.Module's stride, 2 for the ConvTranspose3d roles). */
+size_t ru3d_packed_weight_bytes(int cout, int cin, int k, int stride, int role, int dtype);
 /* src: fp32 weight in the reference's layout (state_dict tensor, contiguous).  dst: packed. */
-int ru3d_pack_weight(const float* src, void* dst, int cout, int cin, int k, int role, int dtype, void* stream);
+int ru3d_pack_weight(const float* src, void* dst, int cout, int cin, int k, int stride, int role, int dtype,
+                     void* stream);
 
 /* ------------------------------------------------------------------ convolutions ------------ */
 /* nn.Conv3d(k in {1,3}, stride in {1,2}, padding=k/2) forward (network.py:394-395,403,541-547).
