@@ -265,6 +265,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
     }
 }
 
+int wgrad_reduce_launch(const float* part, float* dw, int chunks, int taps, int cin, int cout, int64_t s_o, int64_t s_i,
+                        hipStream_t st) {
+    const int64_t total = (int64_t)taps * cin * cout;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, part, dw, chunks, taps, cin, cout, s_o, s_i);
+    return ru3d_check_launch("wgrad_reduce");
+}
+
 int wgrad_generic_chunks(const WgradGeom& g) {
     const int64_t P = (int64_t)g.N * g.Do * g.Ho * g.Wo;
     const int tiles = ((g.Cin + 63) / 64) * ((g.Cout + 63) / 64);
@@ -299,10 +308,5 @@ int wgrad_generic_launch(const void* x, const void* dy, float* dw, void* ws, siz
                            (float*)ws, g);
     int rc = ru3d_check_launch("wgrad_generic");
     if (rc) return rc;
-    const int64_t total = (int64_t)g.taps * g.Cin * g.Cout;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw, chunks, g.taps,
-                       g.Cin, g.Cout, g.s_o, g.s_i);
-    return ru3d_check_launch("wgrad_reduce");
+    return wgrad_reduce_launch((const float*)ws, dw, chunks, g.taps, g.Cin, g.Cout, g.s_o, g.s_i, st);
 }

@@ -230,9 +230,189 @@ int conv_mfma_launch(const void* x, const void* w, const float* bias, const void
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// wgrad: not yet on MFMA
-bool mfma_wgrad_eligible(const WgradGeom&, int) { return false; }
-size_t wgrad_mfma_ws_bytes(const WgradGeom&) { return 0; }
-int wgrad_mfma_launch(const void*, const void*, float*, void*, size_t, WgradGeom, hipStream_t) {
-    return ru3d_fail(-1, "mfma wgrad not built");
+// Weight gradient of the 3x3x3 stride-1 conv on MFMA:
+//     dW[tap][ci][co] = sum_pos X[pos + tap][ci] * DY[pos][co]
+// is 27 GEMMs (M = ci, N = co, K = positions) that share the DY operand.  Both operands are K-major in
+// memory (NDHWC: a position's channels are contiguous, MFMA wants 8 consecutive K per lane), so tiles are
+// staged row-per-position in LDS (64-byte rows, no padding: conflict-free for the transposed read) and the
+// fragments are fetched with ds_read_b64_tr_b16 (hardware 4x16 transpose).
+// Workgroup = one (32 ci) x (32 co) pair; its 4 waves split the 27 taps (7/7/7/6), each wave keeping its
+// taps' 32x32 fp32 accumulators in registers while the workgroup walks position tiles (persistent, stride
+// G).  Partial sums go to a slab per workgroup and are reduced in fixed order (deterministic, no atomics).
+struct MfmaWgradArgs {
+    const bf16* x;
+    const bf16* dy;
+    float* part;
+    int N, D, H, W;
+    int Cin, Cout, ldx, lddy;
+    int tiles_d, tiles_h, tiles_w, ntiles;
+    int G;   // workgroups per channel pair (= number of partial slabs)
+};
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* p) {
+    // 8 consecutive K (positions) of this lane's channel: two 4-row transposed reads
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * 32));
+    bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+
+template <int TD, int TH, int TW>
+__global__ __launch_bounds__(256, 2) void wgrad3_s1_mfma_kernel(MfmaWgradArgs a) {
+    constexpr int HD = TD + 2, HH = TH + 2, WW = TW + 2;
+    constexpr int HV = HD * HH * WW;
+    static_assert(TD * TH * TW == 256, "tile must hold 256 positions");
+    static_assert((HV + 256) * 64 <= 80 * 1024, "two workgroups per CU");
+    __shared__ __attribute__((aligned(16))) bf16 lds[(HV + 256) * 32];
+    bf16* xs = lds;             // [HV][32]  halo tile of 32 input channels
+    bf16* ds = lds + HV * 32;   // [256][32] dy tile of 32 output channels
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int COT = a.Cout / 32;
+    const int cit = blockIdx.y / COT, cot = blockIdx.y % COT;
+
+    // this wave's taps: wave, wave + 4, ... (tap 27 = none)
+    int toff[7];
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        const int tap = wave + 4 * t;
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        toff[t] = ((kd * HH + kh) * WW + kw) * 32;
+    }
+    f32x16 acc[7];
+#pragma unroll
+    for (int t = 0; t < 7; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
+
+    const int h = lane >> 5, cg = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = lane & 3;
+    const int lane_off = q * 32 + 16 * cg + 4 * p4;   // row q of the 4x16 block, columns 4p..4p+3
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += a.G) {
+        int tt = tile;
+        const int w0 = (tt % a.tiles_w) * TW;
+        tt /= a.tiles_w;
+        const int h0 = (tt % a.tiles_h) * TH;
+        tt /= a.tiles_h;
+        const int d0 = (tt % a.tiles_d) * TD;
+        const int n = tt / a.tiles_d;
+        __syncthreads();   // previous tile fully consumed
+        for (int c = tid; c < HV * 4; c += 256) {
+            const int hv = c >> 2, part = c & 3;
+            const int zw = hv % WW, zh = (hv / WW) % HH, zd = hv / (WW * HH);
+            const int gd = d0 + zd - 1, gh = h0 + zh - 1, gw = w0 + zw - 1;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)
+                v = *reinterpret_cast<const bf16x8*>(a.x + ((((int64_t)n * a.D + gd) * a.H + gh) * a.W + gw) * a.ldx +
+                                                     cit * 32 + part * 8);
+            *reinterpret_cast<bf16x8*>(&xs[hv * 32 + part * 8]) = v;
+        }
+        for (int c = tid; c < 256 * 4; c += 256) {
+            const int f = c >> 2, part = c & 3;
+            const int gd = d0 + f / (TH * TW), gh = h0 + (f / TW) % TH, gw = w0 + f % TW;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (gd < a.D && gh < a.H && gw < a.W)
+                v = *reinterpret_cast<const bf16x8*>(a.dy + ((((int64_t)n * a.D + gd) * a.H + gh) * a.W + gw) * a.lddy +
+                                                     cot * 32 + part * 8);
+            *reinterpret_cast<bf16x8*>(&ds[f * 32 + part * 8]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 16; ks++) {
+            // first position of this lane's 8-position half of the k-step: f0 = 16 ks + 8 h
+            int hvb, f0;
+            if (TW >= 16) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int fb = ks * 16;
+                hvb = ((fb / (TH * TW)) * HH + (fb / TW) % TH) * WW + fb % TW + 8 * h;
+                f0 = fb + 8 * h;
+            } else {
+                const int fb = ks * 16;   // two rows of 8: row 2ks (h = 0) and 2ks + 1 (h = 1), same d-plane
+                hvb = ((fb / (TH * TW)) * HH + (fb / TW) % TH) * WW + h * WW;
+                f0 = fb + 8 * h;
+            }
+            const bf16x8 bfrag = tr_frag(ds + f0 * 32 + lane_off);
+#pragma unroll
+            for (int t = 0; t < 7; t++) {
+                if (wave + 4 * t < 27) {
+                    const bf16x8 afrag = tr_frag(xs + hvb * 32 + toff[t] + lane_off);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // partial slab: part[((chunk * 27 + tap) * Cin + ci) * Cout + co]; D row = ci, col = co
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        const int tap = wave + 4 * t;
+        if (tap < 27) {
+            float* pp = a.part + ((int64_t)blockIdx.x * 27 + tap) * a.Cin * a.Cout;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int ci = cit * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                const int co = cot * 32 + (lane & 31);
+                pp[(int64_t)ci * a.Cout + co] = acc[t][i];
+            }
+        }
+    }
+}
+
+bool mfma_wgrad_eligible(const WgradGeom& g, int dtype) {
+    return dtype == RU3D_BF16 && g.k == 3 && g.stride == 1 && (g.Cin % 32) == 0 && (g.Cout % 32) == 0 &&
+           (g.ldx % 8) == 0 && (g.lddy % 8) == 0;
+}
+
+static void wgrad_tiles(const WgradGeom& g, int* td, int* th, int* tw) {
+    if (g.Wo >= 24) { *td = 2; *th = 4; *tw = 32; }
+    else if (g.Wo >= 12) { *td = 2; *th = 8; *tw = 16; }
+    else { *td = 4; *th = 8; *tw = 8; }
+}
+
+static int wgrad_mfma_groups(const WgradGeom& g) {
+    int td, th, tw;
+    wgrad_tiles(g, &td, &th, &tw);
+    const int64_t ntiles = (int64_t)g.N * ((g.Do + td - 1) / td) * ((g.Ho + th - 1) / th) * ((g.Wo + tw - 1) / tw);
+    const int pairs = (g.Cin / 32) * (g.Cout / 32);
+    int64_t G = 512 / pairs;
+    if (G < 1) G = 1;
+    if (G > ntiles) G = ntiles;
+    return (int)G;
+}
+
+size_t wgrad_mfma_ws_bytes(const WgradGeom& g) {
+    return (size_t)wgrad_mfma_groups(g) * 27 * g.Cin * g.Cout * sizeof(float);
+}
+
+int wgrad_mfma_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, WgradGeom g,
+                      hipStream_t st) {
+    const size_t need = wgrad_mfma_ws_bytes(g);
+    if (!ws || ws_bytes < need) return ru3d_fail(-1, "wgrad_mfma: workspace too small (%zu < %zu)", ws_bytes, need);
+    if (!aligned_to(x, 16) || !aligned_to(dy, 16)) return ru3d_fail(-1, "wgrad_mfma: operands must be 16-byte aligned");
+    MfmaWgradArgs a;
+    a.x = (const bf16*)x;
+    a.dy = (const bf16*)dy;
+    a.part = (float*)ws;
+    a.N = g.N; a.D = g.Do; a.H = g.Ho; a.W = g.Wo;
+    a.Cin = g.Cin; a.Cout = g.Cout; a.ldx = g.ldx; a.lddy = g.lddy;
+    int td, th, tw;
+    wgrad_tiles(g, &td, &th, &tw);
+    a.tiles_d = (g.Do + td - 1) / td;
+    a.tiles_h = (g.Ho + th - 1) / th;
+    a.tiles_w = (g.Wo + tw - 1) / tw;
+    a.ntiles = g.N * a.tiles_d * a.tiles_h * a.tiles_w;
+    a.G = wgrad_mfma_groups(g);
+    dim3 grid(a.G, (g.Cin / 32) * (g.Cout / 32));
+    if (tw == 32)
+        hipLaunchKernelGGL((wgrad3_s1_mfma_kernel<2, 4, 32>), grid, dim3(256), 0, st, a);
+    else if (tw == 16)
+        hipLaunchKernelGGL((wgrad3_s1_mfma_kernel<2, 8, 16>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((wgrad3_s1_mfma_kernel<4, 8, 8>), grid, dim3(256), 0, st, a);
+    int rc = ru3d_check_launch("wgrad3_s1_mfma");
+    if (rc) return rc;
+    return wgrad_reduce_launch((const float*)ws, dw, a.G, 27, g.Cin, g.Cout, g.s_o, g.s_i, st);
 }
