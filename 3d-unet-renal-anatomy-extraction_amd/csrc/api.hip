@@ -47,10 +47,11 @@ static void role_channels(int cout, int cin, int role, int* kin, int* kout, int6
     }
 }
 
-// does the kernel that will consume this packed weight run on the MFMA path?  (gather form, k3, stride 1)
+// does the kernel that will consume this packed weight run on the MFMA path?  (all forms; channel counts decide)
 static bool role_uses_mfma(int kin, int kout, int k, int stride, int role, int dtype) {
-    const bool gather_s1 = (role == RU3D_ROLE_CONV_FWD || role == RU3D_ROLE_CONV_DGRAD) && stride == 1;
-    return gather_s1 && mfma_conv_eligible(kin, kout, k, dtype, dtype);
+    (void)stride;
+    (void)role;
+    return mfma_conv_eligible(kin, kout, k, dtype, dtype);
 }
 
 extern "C" size_t ru3d_packed_weight_bytes(int cout, int cin, int k, int stride, int role, int dtype) {

@@ -51,7 +51,7 @@ int pack_mfma_launch(const float* src, void* dst, int cin, int cout, int taps, i
 
 // Which (shape, dtype) combinations take the MFMA path.  Must agree between ru3d_pack_weight and the launchers.
 bool mfma_conv_eligible(int cin, int cout, int k, int dtype, int y_dtype) {
-    return dtype == RU3D_BF16 && y_dtype == RU3D_BF16 && k == 3 && (cin % 32) == 0 && (cout % 32) == 0;
+    return dtype == RU3D_BF16 && y_dtype == RU3D_BF16 && (k == 1 || k == 3) && (cin % 16) == 0 && (cout % 32) == 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -203,11 +203,200 @@ static int launch_s1(const MfmaConvArgs& a0, hipStream_t st) {
     return ru3d_check_launch("conv3_s1_mfma");
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// "Direct" MFMA conv: the activation fragment of every (tap, k-step) is loaded straight from global memory
+// (16 bytes per lane, L1/L2 absorb the tap re-reads), no LDS tile.  Covers every remaining data-movement
+// form of the U-Net with MFMA-friendly channel counts: 1x1x1 convs (stride 1/2), 3x3x3 stride-2 gather
+// (pooling conv, ConvTranspose dgrad) and the transposed form (ConvTranspose fwd, stride-2 conv dgrad).
+// Transposed form: a workgroup owns 32 half-resolution positions x the 8 output parity classes; a wave's
+// column tile holds ONE parity class, so only that class' taps (1/2/4/8 of 27) are issued - no masked MFMAs.
+struct DirectArgs {
+    const bf16* x;
+    const bf16x8* w;
+    const float* bias;
+    const bf16* res;
+    bf16* y;
+    int N, Di, Hi, Wi, Do, Ho, Wo;
+    int Cin, Cout, ldx, ldy, ldr;
+    int k, stride, pad, flip, zero_far;
+    int hd, hh, hw;          // transposed form: half-resolution extents ceil(Do/2)...
+    int64_t total;           // gather: N*Do*Ho*Wo ; transposed: N*hd*hh*hw
+};
+
+template <int NT, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void conv_direct_mfma_kernel(DirectArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NTT = a.Cout / 32, KS = a.Cin / 16;
+    const int co_blk = blockIdx.y * (NT * 32);
+    const int taps = a.k * a.k * a.k;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[m][t][i] = 0.f;
+
+    int n_[2], od[2], oh[2], ow[2];
+    bool valid[2];
+    int ba[2], bb[2], bc[2];   // transposed: half-res coordinates
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        if (!TRANSPOSED) {
+            const int64_t v = (int64_t)blockIdx.x * 256 + (wave * 2 + m) * 32 + (lane & 31);
+            valid[m] = v < a.total;
+            const int64_t vv = valid[m] ? v : 0;
+            ow[m] = (int)(vv % a.Wo);
+            int64_t t = vv / a.Wo;
+            oh[m] = (int)(t % a.Ho);
+            t /= a.Ho;
+            od[m] = (int)(t % a.Do);
+            n_[m] = (int)(t / a.Do);
+            ba[m] = bb[m] = bc[m] = 0;
+        } else {
+            const int64_t hp = (int64_t)blockIdx.x * 32 + (lane & 31);
+            const bool ok = hp < a.total;
+            const int64_t vv = ok ? hp : 0;
+            bc[m] = (int)(vv % a.hw);
+            int64_t t = vv / a.hw;
+            bb[m] = (int)(t % a.hh);
+            t /= a.hh;
+            ba[m] = (int)(t % a.hd);
+            n_[m] = (int)(t / a.hd);
+            const int cl = wave * 2 + m;
+            od[m] = 2 * ba[m] + (cl >> 2);
+            oh[m] = 2 * bb[m] + ((cl >> 1) & 1);
+            ow[m] = 2 * bc[m] + (cl & 1);
+            valid[m] = ok && od[m] < a.Do && oh[m] < a.Ho && ow[m] < a.Wo;
+        }
+    }
+
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const int cl = wave * 2 + m;   // parity class of this column tile (transposed form)
+        for (int kd = 0; kd < a.k; kd++) {
+            int id, qd = 0;
+            if (TRANSPOSED) {
+                qd = (cl >> 2) + a.pad - kd;
+                if (qd & 1) continue;              // wave-uniform: this tap does not feed this parity class
+                id = ba[m] + (qd >> 1);
+            } else {
+                id = od[m] * a.stride + kd - a.pad;
+            }
+            for (int kh = 0; kh < a.k; kh++) {
+                int ih;
+                if (TRANSPOSED) {
+                    const int qh = ((cl >> 1) & 1) + a.pad - kh;
+                    if (qh & 1) continue;
+                    ih = bb[m] + (qh >> 1);
+                } else {
+                    ih = oh[m] * a.stride + kh - a.pad;
+                }
+                for (int kw = 0; kw < a.k; kw++) {
+                    int iw;
+                    if (TRANSPOSED) {
+                        const int qw = (cl & 1) + a.pad - kw;
+                        if (qw & 1) continue;
+                        iw = bc[m] + (qw >> 1);
+                    } else {
+                        iw = ow[m] * a.stride + kw - a.pad;
+                    }
+                    const int tap = (kd * a.k + kh) * a.k + kw;
+                    const int wtap = a.flip ? taps - 1 - tap : tap;
+                    const bool inb = valid[m] && id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+                    const bf16* xp = a.x + ((((int64_t)n_[m] * a.Di + (inb ? id : 0)) * a.Hi + (inb ? ih : 0)) * a.Wi +
+                                            (inb ? iw : 0)) * a.ldx + (lane >> 5) * 8;
+                    const bf16x8* wrow = a.w + ((int64_t)wtap * KS * NTT + blockIdx.y * NT) * 64 + lane;
+#pragma unroll 2
+                    for (int ks = 0; ks < KS; ks++) {
+                        bf16x8 xb = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (inb) xb = *reinterpret_cast<const bf16x8*>(xp + ks * 16);
+#pragma unroll
+                        for (int t = 0; t < NT; t++) {
+                            const bf16x8 wa = wrow[((int64_t)ks * NTT + t) * 64];
+                            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, acc[m][t], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        if (!valid[m]) continue;
+        const int64_t vox = (((int64_t)n_[m] * a.Do + od[m]) * a.Ho + oh[m]) * a.Wo + ow[m];
+        const bool far = a.zero_far && (od[m] == a.Do - 1 || oh[m] == a.Ho - 1 || ow[m] == a.Wo - 1);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int c0 = co_blk + t * 32 + 8 * q + 4 * (lane >> 5);
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[i] = acc[m][t][q * 4 + i];
+                if (a.bias) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + c0);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] += b[i];
+                }
+                if (far) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = 0.f;
+                }
+                if (a.res) {
+                    float r[4];
+                    load_vec<bf16, 4>(a.res + vox * a.ldr + c0, r);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] += r[i];
+                }
+                store_vec<bf16, 4>(a.y + vox * a.ldy + c0, v);
+            }
+        }
+    }
+}
+
+static int launch_direct(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
+                         hipStream_t st) {
+    DirectArgs a;
+    a.x = (const bf16*)x;
+    a.w = (const bf16x8*)w;
+    a.bias = bias;
+    a.res = (const bf16*)res;
+    a.y = (bf16*)y;
+    a.N = g.N; a.Di = g.Di; a.Hi = g.Hi; a.Wi = g.Wi; a.Do = g.Do; a.Ho = g.Ho; a.Wo = g.Wo;
+    a.Cin = g.Cin; a.Cout = g.Cout; a.ldx = g.ldx; a.ldy = g.ldy; a.ldr = g.ldr;
+    a.k = g.k; a.stride = g.stride; a.pad = g.pad; a.flip = g.flip; a.zero_far = g.zero_far;
+    a.hd = (g.Do + 1) / 2; a.hh = (g.Ho + 1) / 2; a.hw = (g.Wo + 1) / 2;
+    const bool nt2 = (g.Cout % 64) == 0;
+    int64_t nblk;
+    if (g.transposed) {
+        if (g.stride != 2) return ru3d_fail(-1, "conv_direct_mfma: transposed form needs stride 2");
+        a.total = (int64_t)g.N * a.hd * a.hh * a.hw;
+        nblk = (a.total + 31) / 32;
+    } else {
+        a.total = (int64_t)g.N * g.Do * g.Ho * g.Wo;
+        nblk = (a.total + 255) / 256;
+    }
+    if (nblk > 0x7fffffff) return ru3d_fail(-1, "conv_direct_mfma: grid too large");
+    dim3 grid((unsigned)nblk, g.Cout / (nt2 ? 64 : 32));
+    if (g.transposed) {
+        if (nt2) hipLaunchKernelGGL((conv_direct_mfma_kernel<2, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_direct_mfma_kernel<1, true>), grid, dim3(256), 0, st, a);
+    } else {
+        if (nt2) hipLaunchKernelGGL((conv_direct_mfma_kernel<2, false>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_direct_mfma_kernel<1, false>), grid, dim3(256), 0, st, a);
+    }
+    return ru3d_check_launch("conv_direct_mfma");
+}
+
 static bool aligned_to(const void* p, size_t a) { return (((uintptr_t)p) % a) == 0; }
 
-// Shapes the LDS-halo MFMA kernel takes; everything else MFMA-"eligible" by channel count still runs on the
-// generic kernel with the generic weight layout -> keep this predicate consistent with packing (see api.hip).
-bool mfma_conv_geometry_ok(const ConvGeom& g) { return g.k == 3 && g.stride == 1 && !g.transposed; }
+// Every data-movement form with MFMA-friendly channel counts runs on MFMA: the 3x3x3 stride-1 gather with
+// Cin % 32 == 0 on the LDS-halo kernel, everything else on the direct kernel (same packed-weight layout).
+bool mfma_conv_geometry_ok(const ConvGeom& g) { return !g.transposed || g.stride == 2; }
 
 int conv_mfma_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
                      hipStream_t st) {
@@ -215,6 +404,8 @@ int conv_mfma_launch(const void* x, const void* w, const float* bias, const void
     if ((g.ldx % 8) || (g.ldy % 4) || (res && (g.ldr % 4)) || !aligned_to(x, 16) || !aligned_to(y, 8) ||
         (res && !aligned_to(res, 8)) || (bias && !aligned_to(bias, 16)) || !aligned_to(w, 16))
         return ru3d_fail(-1, "conv_mfma: operands must be 16-byte (x, w, bias) / 8-byte (y, res) aligned");
+    if (!(g.k == 3 && g.stride == 1 && !g.transposed && (g.Cin % 32) == 0))
+        return launch_direct(x, w, bias, res, y, g, st);
     MfmaConvArgs a;
     a.x = (const bf16*)x;
     a.w = (const bf16x8*)w;

@@ -412,6 +412,69 @@ def test_mfma_conv_s1_bf16(shape):
     _close(gw, wr.grad, 2e-3, 1e-3, "wgrad %s" % (shape,))
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,dims", [(32, 64, 3, 2, (7, 9, 11)), (32, 64, 3, 2, (8, 8, 16)),
+                                                    (64, 32, 1, 1, (5, 6, 7)), (32, 64, 1, 2, (7, 8, 9)),
+                                                    (16, 32, 3, 1, (4, 5, 9)), (48, 96, 3, 2, (6, 6, 6))])
+def test_mfma_direct_conv_forms_bf16(cin, cout, k, stride, dims):
+    """Direct-load MFMA kernel: 1x1x1 (stride 1/2), 3x3x3 stride 2, Cin % 32 != 0; forward (gather form),
+    input gradient (transposed form for stride 2) with a fused residual, on ragged extents."""
+    g = torch.Generator().manual_seed(cin + cout + k + stride)
+    d, h, w = dims
+    xv = torch.randn(2, cin, d, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, k, generator=g) * (1.0 / (k ** 3 * cin) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    x = ops.as_input(xv.to(DEV), torch.bfloat16)
+    pw = ops.pack_weight(wt.to(DEV), N.ROLE_CONV_FWD, torch.bfloat16, stride)
+    y = ops.conv_fwd(x, pw, b.to(DEV), cout, k, stride)
+    xr = xv.bfloat16().float().requires_grad_(True)
+    wr = wt.bfloat16().float().requires_grad_(True)
+    ref = torch.nn.functional.conv3d(xr, wr, b, stride=stride, padding=k // 2)
+    _close(y, ref, 2 ** -8, 1e-3, "direct fwd")
+    gy = torch.randn(ref.shape, generator=g)
+    rv = torch.randn(xv.shape, generator=g)
+    gyd = ops.as_input(gy.to(DEV), torch.bfloat16)
+    res = ops.as_input(rv.to(DEV), torch.bfloat16)
+    pwd = ops.pack_weight(wt.to(DEV), N.ROLE_CONV_DGRAD, torch.bfloat16, stride)
+    gx = ops.conv_dgrad(gyd, pwd, tuple(xv.shape), k, stride, res=res)
+    ref.backward(gy.bfloat16().float())
+    _close(gx, xr.grad + rv.bfloat16().float(), 2 ** -8, 2e-3, "direct dgrad")
+    gw = ops.conv_wgrad(x, gyd, k, stride)
+    _close(gw, wr.grad, 2e-3, 1e-3, "wgrad")
+
+
+@pytest.mark.parametrize("cin,cout,dims", [(64, 32, (3, 4, 5)), (32, 32, (4, 4, 8)), (128, 64, (2, 3, 3))])
+def test_mfma_convtranspose_bf16(cin, cout, dims):
+    """ConvTranspose3d(k3,s2,p1) + far zero pad on the MFMA transposed form (parity classes), its input
+    gradient (stride-2 gather) and weight gradient, vs torch CPU on bf16-rounded operands."""
+    g = torch.Generator().manual_seed(cin + cout)
+    d, h, w = dims
+    xv = torch.randn(2, cin, d, h, w, generator=g)
+    wt = torch.randn(cin, cout, 3, 3, 3, generator=g) * (1.0 / (27 * cin / 8) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    x = ops.as_input(xv.to(DEV), torch.bfloat16)
+    pw = ops.pack_weight(wt.to(DEV), N.ROLE_CONVT_FWD, torch.bfloat16)
+    y = ops.convt_fwd(x, pw, b.to(DEV), cout)
+    xr = xv.bfloat16().float().requires_grad_(True)
+    wr = wt.bfloat16().float().requires_grad_(True)
+    ref = torch.nn.functional.pad(torch.nn.functional.conv_transpose3d(xr, wr, b, stride=2, padding=1),
+                                  (0, 1, 0, 1, 0, 1))
+    _close(y, ref, 2 ** -8, 1e-3, "convT fwd")
+    yc = y.float().cpu()
+    assert float(yc[:, :, -1].abs().max()) == 0 and float(yc[:, :, :, -1].abs().max()) == 0 \
+        and float(yc[..., -1].abs().max()) == 0
+    gy = torch.randn(ref.shape, generator=g)
+    gy[:, :, -1] = 0
+    gy[:, :, :, -1] = 0
+    gy[..., -1] = 0                         # contract: dy has zero far planes
+    gyd = ops.as_input(gy.to(DEV), torch.bfloat16)
+    pwd = ops.pack_weight(wt.to(DEV), N.ROLE_CONVT_DGRAD, torch.bfloat16)
+    gx = ops.convt_dgrad(gyd, pwd, tuple(xv.shape))
+    ref.backward(gy.bfloat16().float())
+    _close(gx, xr.grad, 2 ** -8, 2e-3, "convT dgrad")
+    gw = ops.convt_wgrad(x, gyd)
+    _close(gw, wr.grad, 2e-3, 1e-3, "convT wgrad")
+
+
 def test_norm_kernels_vs_oracle_bf16_and_fp32():
     g = torch.Generator().manual_seed(12)
     for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
