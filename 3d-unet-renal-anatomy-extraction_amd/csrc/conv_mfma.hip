@@ -552,9 +552,141 @@ __global__ __launch_bounds__(256, 2) void wgrad3_s1_mfma_kernel(MfmaWgradArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient for the remaining forms (1x1x1 stride 1/2; 3x3x3 stride 2 = pooling conv and ConvTranspose):
+// the gathered operand X[s*pos + tap - p] has no compact halo, so each tap's [positions][32 ci] tile is staged
+// separately (row-per-position, transposed reads as above).
+//   TAPS == 27: tile = 32 flat positions, all 27 tap tiles resident (55 KB); waves split the taps.
+//   TAPS == 1 : tile = 256 flat positions; waves split the K (position) range and write one slab each.
+struct StagedWgradArgs {
+    const bf16* x;
+    const bf16* dy;
+    float* part;
+    int N, Di, Hi, Wi, Do, Ho, Wo;
+    int Cin, Cout, ldx, lddy;
+    int stride, pad;
+    int64_t P;       // N*Do*Ho*Wo
+    int ntiles, G;
+};
+
+template <int TAPS, int PT>
+__global__ __launch_bounds__(256, 2) void wgrad_staged_mfma_kernel(StagedWgradArgs a) {
+    constexpr int K = (TAPS == 27) ? 3 : 1;
+    __shared__ __attribute__((aligned(16))) bf16 lds[(TAPS * PT + PT) * 32];
+    bf16* xs = lds;                    // [TAPS][PT][32]
+    bf16* ds = lds + TAPS * PT * 32;   // [PT][32]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int COT = a.Cout / 32;
+    const int cit = blockIdx.y / COT, cot = blockIdx.y % COT;
+    constexpr int NACC = (TAPS == 27) ? 7 : 1;
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int t = 0; t < NACC; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
+    const int h = lane >> 5, cg = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = lane & 3;
+    const int lane_off = q * 32 + 16 * cg + 4 * p4;
+    const int part = tid & 3;
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += a.G) {
+        const int64_t p_base = (int64_t)tile * PT;
+        __syncthreads();
+        // each thread stages a fixed 16-byte piece column (part) of fixed positions for every tap it owns
+        constexpr int POS_PER_THREAD = (PT * 4 + 255) / 256;      // 4 for PT = 256, 1 for PT = 32
+#pragma unroll
+        for (int j = 0; j < POS_PER_THREAD; j++) {
+            const int pl = ((tid >> 2) + 64 * j) % PT;
+            const int64_t pos = p_base + pl;
+            const bool pv = pos < a.P;
+            const int64_t pp = pv ? pos : 0;
+            const int ow = (int)(pp % a.Wo);
+            int64_t t = pp / a.Wo;
+            const int oh = (int)(t % a.Ho);
+            t /= a.Ho;
+            const int od = (int)(t % a.Do);
+            const int n = (int)(t / a.Do);
+            // dy piece (only the threads of the first 4*PT ids, i.e. every (pos, part) once)
+            if (TAPS == 1 || tid < PT * 4) {
+                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (pv) v = *reinterpret_cast<const bf16x8*>(a.dy + pos * a.lddy + cot * 32 + part * 8);
+                *reinterpret_cast<bf16x8*>(&ds[pl * 32 + part * 8]) = v;
+            }
+            // taps owned by this thread: TAPS == 27 -> (tid >> 7) + 2 i ; TAPS == 1 -> tap 0
+            constexpr int TAP_ITERS = (TAPS == 27) ? 14 : 1;
+#pragma unroll
+            for (int i = 0; i < TAP_ITERS; i++) {
+                const int tap = (TAPS == 27) ? ((tid >> 7) + 2 * i) : 0;
+                if (tap >= TAPS) break;
+                const int kd = tap / (K * K), kh = (tap / K) % K, kw = tap % K;
+                const int id = od * a.stride + kd - a.pad, ih = oh * a.stride + kh - a.pad,
+                          iw = ow * a.stride + kw - a.pad;
+                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (pv && id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+                    v = *reinterpret_cast<const bf16x8*>(a.x + ((((int64_t)n * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.ldx +
+                                                         cit * 32 + part * 8);
+                *reinterpret_cast<bf16x8*>(&xs[(tap * PT + pl) * 32 + part * 8]) = v;
+            }
+        }
+        __syncthreads();
+        if (TAPS == 27) {
+#pragma unroll
+            for (int ks = 0; ks < PT / 16; ks++) {
+                const int f0 = ks * 16 + 8 * h;
+                const bf16x8 bfrag = tr_frag(ds + f0 * 32 + lane_off);
+#pragma unroll
+                for (int t = 0; t < NACC; t++) {
+                    const int tap = wave + 4 * t;
+                    if (tap < 27) {
+                        const bf16x8 afrag = tr_frag(xs + (tap * PT + f0) * 32 + lane_off);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < PT / 64; kk++) {
+                const int f0 = (wave * (PT / 64) + kk) * 16 + 8 * h;
+                const bf16x8 bfrag = tr_frag(ds + f0 * 32 + lane_off);
+                const bf16x8 afrag = tr_frag(xs + f0 * 32 + lane_off);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[0], 0, 0, 0);
+            }
+        }
+    }
+    // slabs: TAPS == 27: one per workgroup (chunk = blockIdx.x); TAPS == 1: one per wave (chunk = 4 blockIdx.x + wave)
+#pragma unroll
+    for (int t = 0; t < NACC; t++) {
+        const int tap = (TAPS == 27) ? wave + 4 * t : 0;
+        if (tap < TAPS) {
+            const int64_t chunk = (TAPS == 27) ? blockIdx.x : (int64_t)blockIdx.x * 4 + wave;
+            float* pp = a.part + (chunk * TAPS + tap) * a.Cin * a.Cout;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int ci = cit * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                const int co = cot * 32 + (lane & 31);
+                pp[(int64_t)ci * a.Cout + co] = acc[t][i];
+            }
+        }
+    }
+}
+
+static bool wgrad_is_halo_form(const WgradGeom& g) { return g.k == 3 && g.stride == 1; }
+
+static int staged_groups(const WgradGeom& g) {
+    const int64_t P = (int64_t)g.N * g.Do * g.Ho * g.Wo;
+    const int pt = (g.k == 3) ? 32 : 256;
+    const int64_t ntiles = (P + pt - 1) / pt;
+    const int pairs = (g.Cin / 32) * (g.Cout / 32);
+    int64_t G = 1024 / pairs;
+    if (G < 1) G = 1;
+    if (G > ntiles) G = ntiles;
+    return (int)G;
+}
+
 bool mfma_wgrad_eligible(const WgradGeom& g, int dtype) {
-    return dtype == RU3D_BF16 && g.k == 3 && g.stride == 1 && (g.Cin % 32) == 0 && (g.Cout % 32) == 0 &&
-           (g.ldx % 8) == 0 && (g.lddy % 8) == 0;
+    const bool form = (g.k == 3 && (g.stride == 1 || g.stride == 2)) || g.k == 1;
+    return dtype == RU3D_BF16 && form && (g.Cin % 32) == 0 && (g.Cout % 32) == 0 && (g.ldx % 8) == 0 &&
+           (g.lddy % 8) == 0;
 }
 
 static void wgrad_tiles(const WgradGeom& g, int* td, int* th, int* tw) {
@@ -575,7 +707,37 @@ static int wgrad_mfma_groups(const WgradGeom& g) {
 }
 
 size_t wgrad_mfma_ws_bytes(const WgradGeom& g) {
-    return (size_t)wgrad_mfma_groups(g) * 27 * g.Cin * g.Cout * sizeof(float);
+    if (wgrad_is_halo_form(g)) return (size_t)wgrad_mfma_groups(g) * 27 * g.Cin * g.Cout * sizeof(float);
+    const int slabs = staged_groups(g) * (g.k == 1 ? 4 : 1);
+    return (size_t)slabs * g.taps * g.Cin * g.Cout * sizeof(float);
+}
+
+static int wgrad_staged_launch(const void* x, const void* dy, float* dw, void* ws, const WgradGeom& g, hipStream_t st) {
+    StagedWgradArgs a;
+    a.x = (const bf16*)x;
+    a.dy = (const bf16*)dy;
+    a.part = (float*)ws;
+    a.N = g.N; a.Di = g.Di; a.Hi = g.Hi; a.Wi = g.Wi; a.Do = g.Do; a.Ho = g.Ho; a.Wo = g.Wo;
+    a.Cin = g.Cin; a.Cout = g.Cout; a.ldx = g.ldx; a.lddy = g.lddy;
+    a.stride = g.stride; a.pad = g.pad;
+    a.P = (int64_t)g.N * g.Do * g.Ho * g.Wo;
+    const int pt = (g.k == 3) ? 32 : 256;
+    const int64_t ntiles = (a.P + pt - 1) / pt;
+    if (ntiles > 0x7fffffff) return ru3d_fail(-1, "wgrad_staged: too many tiles");
+    a.ntiles = (int)ntiles;
+    a.G = staged_groups(g);
+    dim3 grid(a.G, (g.Cin / 32) * (g.Cout / 32));
+    int slabs;
+    if (g.k == 3) {
+        hipLaunchKernelGGL((wgrad_staged_mfma_kernel<27, 32>), grid, dim3(256), 0, st, a);
+        slabs = a.G;
+    } else {
+        hipLaunchKernelGGL((wgrad_staged_mfma_kernel<1, 256>), grid, dim3(256), 0, st, a);
+        slabs = a.G * 4;
+    }
+    int rc = ru3d_check_launch("wgrad_staged_mfma");
+    if (rc) return rc;
+    return wgrad_reduce_launch((const float*)ws, dw, slabs, g.taps, g.Cin, g.Cout, g.s_o, g.s_i, st);
 }
 
 int wgrad_mfma_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, WgradGeom g,
@@ -583,6 +745,7 @@ int wgrad_mfma_launch(const void* x, const void* dy, float* dw, void* ws, size_t
     const size_t need = wgrad_mfma_ws_bytes(g);
     if (!ws || ws_bytes < need) return ru3d_fail(-1, "wgrad_mfma: workspace too small (%zu < %zu)", ws_bytes, need);
     if (!aligned_to(x, 16) || !aligned_to(dy, 16)) return ru3d_fail(-1, "wgrad_mfma: operands must be 16-byte aligned");
+    if (!wgrad_is_halo_form(g)) return wgrad_staged_launch(x, dy, dw, ws, g, st);
     MfmaWgradArgs a;
     a.x = (const bf16*)x;
     a.dy = (const bf16*)dy;
