@@ -92,6 +92,7 @@ static int run_conv(const ru3d_tensor* x, const void* w, const float* bias, cons
     g.ldr = res ? res->ld : 0;
     g.k = k; g.stride = stride; g.pad = k / 2;
     g.transposed = transposed; g.zero_far = zero_far; g.flip = flip;
+    if (stem_fwd_eligible(g, dtype, y_dtype, res)) return stem_fwd_launch(x->ptr, w, bias, y->ptr, g, dtype, st);
     if (mfma_conv_eligible(g.Cin, g.Cout, k, dtype, y_dtype) && mfma_conv_geometry_ok(g))
         return conv_mfma_launch(x->ptr, w, bias, res ? res->ptr : nullptr, y->ptr, g, st);
     return conv_generic_launch(x->ptr, w, bias, res ? res->ptr : nullptr, y->ptr, g, dtype, y_dtype, st);
@@ -152,6 +153,8 @@ extern "C" size_t ru3d_conv3d_wgrad_workspace_bytes(const ru3d_tensor* x, const 
                                                     int dtype) {
     if (!wgrad_shapes_ok(x, dy, k, stride)) return 0;
     WgradGeom g = make_wgrad(x, dy, k, stride);
+    if (stem_wgrad_eligible(g)) return stem_wgrad_ws_bytes(g);
+    if (head_wgrad_eligible(g, dtype)) return head_wgrad_ws_bytes(g);
     if (mfma_wgrad_eligible(g, dtype)) return wgrad_mfma_ws_bytes(g);
     return wgrad_generic_ws_bytes(g);
 }
@@ -162,6 +165,9 @@ extern "C" int ru3d_conv3d_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, fl
     RU3D_REQUIRE(wgrad_shapes_ok(x, dy, k, stride), "conv3d_wgrad: x/dy shape mismatch");
     RU3D_REQUIRE(dw && dtype_ok(dtype), "conv3d_wgrad: bad argument");
     WgradGeom g = make_wgrad(x, dy, k, stride);
+    if (stem_wgrad_eligible(g)) return stem_wgrad_launch(x->ptr, dy->ptr, dw, ws, ws_bytes, g, dtype, as_stream(stream));
+    if (head_wgrad_eligible(g, dtype))
+        return head_wgrad_launch(x->ptr, dy->ptr, dw, ws, ws_bytes, g, dtype, as_stream(stream));
     if (mfma_wgrad_eligible(g, dtype)) return wgrad_mfma_launch(x->ptr, dy->ptr, dw, ws, ws_bytes, g, as_stream(stream));
     return wgrad_generic_launch(x->ptr, dy->ptr, dw, ws, ws_bytes, g, dtype, as_stream(stream));
 }

@@ -48,3 +48,16 @@ bool mfma_wgrad_eligible(const WgradGeom& g, int dtype);
 size_t wgrad_mfma_ws_bytes(const WgradGeom& g);
 int wgrad_mfma_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, WgradGeom g,
                       hipStream_t st);
+
+// small_convs.hip (1-channel stem, 2..4-channel head)
+bool stem_fwd_eligible(const ConvGeom& g, int dtype, int y_dtype, const void* res);
+int stem_fwd_launch(const void* x, const void* w, const float* bias, void* y, const ConvGeom& g, int dtype,
+                    hipStream_t st);
+bool stem_wgrad_eligible(const WgradGeom& g);
+size_t stem_wgrad_ws_bytes(const WgradGeom& g);
+int stem_wgrad_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, const WgradGeom& g,
+                      int dtype, hipStream_t st);
+bool head_wgrad_eligible(const WgradGeom& g, int dtype);
+size_t head_wgrad_ws_bytes(const WgradGeom& g);
+int head_wgrad_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, const WgradGeom& g,
+                      int dtype, hipStream_t st);

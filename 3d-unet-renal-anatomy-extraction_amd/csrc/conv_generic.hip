@@ -251,16 +251,26 @@ __global__ __launch_bounds__(256) void wgrad_generic_kernel(const T* __restrict_
 }
 
 // dw[co*s_o + ci*s_i + tap] = sum_chunk part[chunk][tap][ci][co]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int chunks, int taps,
-                                    int cin, int cout, int64_t s_o, int64_t s_i) {
+// block = 64 consecutive outputs x 4 chunk lanes (coalesced slab reads); the 4 lane sums are combined in a
+// fixed order -> deterministic.  Small chunk counts use 1 lane per output.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           int chunks, int taps, int cin, int cout, int64_t s_o,
+                                                           int64_t s_i) {
+    __shared__ float sh[4][64];
     const int64_t total = (int64_t)taps * cin * cout;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int c = 0; c < chunks; c++) s += part[(int64_t)c * total + i];
-        int co = (int)(i % cout);
-        int64_t t = i / cout;
-        int ci = (int)(t % cin);
-        int tap = (int)(t / cin);
+    const int ox = threadIdx.x & 63, ky = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + ox;
+    float s = 0.f;
+    if (i < total)
+        for (int c = ky; c < chunks; c += 4) s += part[(int64_t)c * total + i];
+    sh[ky][ox] = s;
+    __syncthreads();
+    if (ky == 0 && i < total) {
+        s = (sh[0][ox] + sh[1][ox]) + (sh[2][ox] + sh[3][ox]);
+        const int co = (int)(i % cout);
+        const int64_t t = i / cout;
+        const int ci = (int)(t % cin);
+        const int tap = (int)(t / cin);
         dw[co * s_o + ci * s_i + tap] = s;
     }
 }
@@ -268,9 +278,10 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __res
 int wgrad_reduce_launch(const float* part, float* dw, int chunks, int taps, int cin, int cout, int64_t s_o, int64_t s_i,
                         hipStream_t st) {
     const int64_t total = (int64_t)taps * cin * cout;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, part, dw, chunks, taps, cin, cout, s_o, s_i);
+    const int64_t blocks = (total + 63) / 64;
+    if (blocks > 0x7fffffff) return ru3d_fail(-1, "wgrad_reduce: grid too large");
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, dw, chunks, taps, cin, cout,
+                       s_o, s_i);
     return ru3d_check_launch("wgrad_reduce");
 }
 

@@ -137,19 +137,48 @@ __global__ __launch_bounds__(256) void reduce2_kernel(const T* __restrict__ a, i
     }
 }
 
-// stats finalize: mean, scale = s / sqrt(s^2 var + eps)
-__global__ void stats_finalize_kernel(const double* __restrict__ part, int chunks, int C, int NC, double invV,
-                                      const float* __restrict__ drop, float eps, float* __restrict__ mean,
-                                      float* __restrict__ scale) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= NC) return;
-    const int n = i / C, c = i % C;
-    double t1 = 0.0, t2 = 0.0;
-    for (int k = 0; k < chunks; k++) {
-        const double* pp = part + (((int64_t)n * chunks + k) * C + c) * 2;
-        t1 += pp[0];
-        t2 += pp[1];
+// Finalize kernels: 16 channel lanes x 16 chunk lanes per block; every lane sums a strided subset of the
+// per-block partials in double, the 16 subsets are combined in a fixed order through LDS (deterministic).
+#define FIN_CX 16
+#define FIN_KY 16
+__device__ __forceinline__ void finalize_sums(const double* __restrict__ part, int rows, int64_t row_stride, int c,
+                                              bool ok, double& t1, double& t2) {
+    // rows = number of partial rows for this (n) (or N*chunks for channel sums); row r at part + r*row_stride + c*2
+    __shared__ double sh[2][FIN_KY][FIN_CX];
+    const int cx = threadIdx.x % FIN_CX, ky = threadIdx.x / FIN_CX;
+    double a1 = 0.0, a2 = 0.0;
+    if (ok) {
+        for (int r = ky; r < rows; r += FIN_KY) {
+            const double* pp = part + (int64_t)r * row_stride + (int64_t)c * 2;
+            a1 += pp[0];
+            a2 += pp[1];
+        }
     }
+    sh[0][ky][cx] = a1;
+    sh[1][ky][cx] = a2;
+    __syncthreads();
+    t1 = 0.0;
+    t2 = 0.0;
+    if (ky == 0) {
+#pragma unroll
+        for (int k = 0; k < FIN_KY; k++) {
+            t1 += sh[0][k][cx];
+            t2 += sh[1][k][cx];
+        }
+    }
+}
+
+// stats finalize: mean, scale = s / sqrt(s^2 var + eps)
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const double* __restrict__ part, int chunks, int C,
+                                                             int NC, double invV, const float* __restrict__ drop,
+                                                             float eps, float* __restrict__ mean,
+                                                             float* __restrict__ scale) {
+    const int i = blockIdx.x * FIN_CX + threadIdx.x % FIN_CX;
+    const bool ok = i < NC;
+    const int n = ok ? i / C : 0, c = ok ? i % C : 0;
+    double t1, t2;
+    finalize_sums(part + (int64_t)n * chunks * C * 2, chunks, (int64_t)C * 2, c, ok, t1, t2);
+    if (!ok || threadIdx.x >= FIN_CX) return;
     const double m = t1 * invV;
     double var = t2 * invV - m * m;
     if (var < 0.0) var = 0.0;
@@ -159,29 +188,26 @@ __global__ void stats_finalize_kernel(const double* __restrict__ part, int chunk
 }
 
 // backward finalize: m1 = mean(gpre), m2 = mean(gpre * xhat), stored right after the partials
-__global__ void bwd_finalize_kernel(const double* __restrict__ part, int chunks, int C, int NC, double invV,
-                                    float* __restrict__ m12) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= NC) return;
-    const int n = i / C, c = i % C;
-    double t1 = 0.0, t2 = 0.0;
-    for (int k = 0; k < chunks; k++) {
-        const double* pp = part + (((int64_t)n * chunks + k) * C + c) * 2;
-        t1 += pp[0];
-        t2 += pp[1];
-    }
+__global__ __launch_bounds__(256) void bwd_finalize_kernel(const double* __restrict__ part, int chunks, int C, int NC,
+                                                           double invV, float* __restrict__ m12) {
+    const int i = blockIdx.x * FIN_CX + threadIdx.x % FIN_CX;
+    const bool ok = i < NC;
+    const int n = ok ? i / C : 0, c = ok ? i % C : 0;
+    double t1, t2;
+    finalize_sums(part + (int64_t)n * chunks * C * 2, chunks, (int64_t)C * 2, c, ok, t1, t2);
+    if (!ok || threadIdx.x >= FIN_CX) return;
     m12[2 * i] = (float)(t1 * invV);
     m12[2 * i + 1] = (float)(t2 * invV);
 }
 
-__global__ void chansum_finalize_kernel(const double* __restrict__ part, int chunks, int C, int N,
-                                        float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double t = 0.0;
-    for (int n = 0; n < N; n++)
-        for (int k = 0; k < chunks; k++) t += part[(((int64_t)n * chunks + k) * C + c) * 2];
-    out[c] = (float)t;
+__global__ __launch_bounds__(256) void chansum_finalize_kernel(const double* __restrict__ part, int chunks, int C,
+                                                               int N, float* __restrict__ out) {
+    const int c = blockIdx.x * FIN_CX + threadIdx.x % FIN_CX;
+    const bool ok = c < C;
+    double t1, t2;
+    finalize_sums(part, N * chunks, (int64_t)C * 2, ok ? c : 0, ok, t1, t2);
+    if (!ok || threadIdx.x >= FIN_CX) return;
+    out[c] = (float)t1;
 }
 
 // --------------------------------------------------------------------------- apply kernels
@@ -335,7 +361,7 @@ static int stats_impl(const ru3d_tensor* y, const float* drop, float* mean, floa
     int rc = ru3d_check_launch("instnorm_stats");
     if (rc) return rc;
     const int NC = y->n * y->c;
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((NC + 255) / 256), dim3(256), 0, st, (const double*)part, cl.chunks,
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((NC + FIN_CX - 1) / FIN_CX), dim3(256), 0, st, (const double*)part, cl.chunks,
                        y->c, NC, 1.0 / (double)V, drop, eps, mean, scale);
     return ru3d_check_launch("instnorm_stats_finalize");
 }
@@ -400,7 +426,7 @@ static int in_bwd_impl(const ru3d_tensor* gout, const ru3d_tensor* out, const ru
 #undef CALL
     int rc = ru3d_check_launch("in_lrelu_bwd_reduce");
     if (rc) return rc;
-    hipLaunchKernelGGL(bwd_finalize_kernel, dim3((NC + 255) / 256), dim3(256), 0, st, (const double*)part, cl.chunks,
+    hipLaunchKernelGGL(bwd_finalize_kernel, dim3((NC + FIN_CX - 1) / FIN_CX), dim3(256), 0, st, (const double*)part, cl.chunks,
                        y->c, NC, 1.0 / (double)V, m12);
     rc = ru3d_check_launch("in_lrelu_bwd_finalize");
     if (rc) return rc;
@@ -454,7 +480,7 @@ static int chansum_impl(const ru3d_tensor* t, float* out, void* ws, hipStream_t 
 #undef CALL
     int rc = ru3d_check_launch("channel_sum");
     if (rc) return rc;
-    hipLaunchKernelGGL(chansum_finalize_kernel, dim3((t->c + 255) / 256), dim3(256), 0, st, (const double*)part,
+    hipLaunchKernelGGL(chansum_finalize_kernel, dim3((t->c + FIN_CX - 1) / FIN_CX), dim3(256), 0, st, (const double*)part,
                        cl.chunks, t->c, t->n, out);
     return ru3d_check_launch("channel_sum_finalize");
 }

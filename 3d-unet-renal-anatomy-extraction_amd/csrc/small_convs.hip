@@ -1,0 +1,241 @@
+// Dedicated kernels for the two "thin" ends of the U-Net, where one side of the conv has 1..4 channels and
+// an implicit GEMM would be almost all padding.  Both are HBM-bound by construction:
+//   stem  : Conv3d(1 -> F, k3, p1)          forward and weight gradient  (reference network.py:541-544)
+//   head  : Conv3d(F -> classes, k1)        weight gradient              (reference network.py:545-547)
+// (The head forward / input gradient and the stem forward for other shapes stay on conv_generic.hip.)
+#include "common.h"
+#include "conv.h"
+
+// --------------------------------------------------------------------------- stem forward (Cin == 1)
+// thread = (voxel, group of 8 couts): 27 scalar x loads (neighbouring lanes share them through L1), 27x8 FMA,
+// one 16-byte (bf16) / 32-byte (f32) store; consecutive lanes write consecutive channel groups of consecutive
+// voxels -> fully coalesced NDHWC stores.  Weights [27][CoutPad] (generic packing) are staged in LDS as fp32.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                       const float* __restrict__ bias, T* __restrict__ y, ConvGeom g) {
+    extern __shared__ float wl[];   // [27][Cout] + [Cout]
+    const int Cout = g.Cout;
+    for (int i = threadIdx.x; i < 27 * Cout; i += 256) wl[i] = to_f32<T>(w[(i / Cout) * g.CoutPad + (i % Cout)]);
+    for (int i = threadIdx.x; i < Cout; i += 256) wl[27 * Cout + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const int groups = Cout / 8;
+    const int64_t total = (int64_t)g.N * g.Do * g.Ho * g.Wo * groups;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int cg = (int)(gid % groups);
+    const int64_t vo = gid / groups;
+    const int ow = (int)(vo % g.Wo);
+    int64_t t = vo / g.Wo;
+    const int oh = (int)(t % g.Ho);
+    t /= g.Ho;
+    const int od = (int)(t % g.Do);
+    const int n = (int)(t / g.Do);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = wl[27 * Cout + cg * 8 + j];
+#pragma unroll
+    for (int kd = 0; kd < 3; kd++) {
+        const int id = od + kd - 1;
+        if (id < 0 || id >= g.Di) continue;
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++) {
+            const int ih = oh + kh - 1;
+            if (ih < 0 || ih >= g.Hi) continue;
+            const T* row = x + (((int64_t)n * g.Di + id) * g.Hi + ih) * g.Wi * g.ldx;
+#pragma unroll
+            for (int kw = 0; kw < 3; kw++) {
+                const int iw = ow + kw - 1;
+                if (iw < 0 || iw >= g.Wi) continue;
+                const float xv = to_f32<T>(row[(int64_t)iw * g.ldx]);
+                const float* wr = wl + ((kd * 3 + kh) * 3 + kw) * Cout + cg * 8;
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[j] = fmaf(xv, wr[j], acc[j]);
+            }
+        }
+    }
+    store_vec<T, 8>(y + vo * g.ldy + cg * 8, acc);
+}
+
+bool stem_fwd_eligible(const ConvGeom& g, int dtype, int y_dtype, const void* res) {
+    return g.Cin == 1 && g.k == 3 && g.stride == 1 && !g.transposed && !g.flip && !g.zero_far && !res &&
+           dtype == y_dtype && (g.Cout % 8) == 0 && g.Cout <= 256 && (g.ldy % 8) == 0;
+}
+
+int stem_fwd_launch(const void* x, const void* w, const float* bias, void* y, const ConvGeom& g, int dtype,
+                    hipStream_t st) {
+    const int64_t total = (int64_t)g.N * g.Do * g.Ho * g.Wo * (g.Cout / 8);
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffff) return ru3d_fail(-1, "stem_fwd: grid too large");
+    const size_t lds = (size_t)28 * g.Cout * sizeof(float);
+    if (dtype == RU3D_F32)
+        hipLaunchKernelGGL(stem_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, st, (const float*)x,
+                           (const float*)w, bias, (float*)y, g);
+    else
+        hipLaunchKernelGGL(stem_fwd_kernel<bf16>, dim3((unsigned)blocks), dim3(256), lds, st, (const bf16*)x,
+                           (const bf16*)w, bias, (bf16*)y, g);
+    return ru3d_check_launch("stem_fwd");
+}
+
+// --------------------------------------------------------------------------- stem weight gradient (Cin == 1)
+// dW[tap][co] = sum_pos x[pos + tap] * dy[pos][co].  Workgroup = a run of STEM_CHUNK flat positions x 32 couts;
+// wave = 8 couts; lanes stride over positions; the three kd planes are processed one after the other so a
+// lane holds 9 taps x 8 couts of partial sums (72 VGPRs).  Lane sums are combined with a shuffle tree and
+// one slab per workgroup is reduced afterwards in fixed order (deterministic).
+#define STEM_CHUNK 2048
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                         float* __restrict__ part, WgradGeom g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int co0 = blockIdx.y * 32 + wave * 8;
+    const int64_t P = (int64_t)g.N * g.Do * g.Ho * g.Wo;
+    const int64_t p0 = (int64_t)blockIdx.x * STEM_CHUNK;
+    int64_t p1 = p0 + STEM_CHUNK;
+    if (p1 > P) p1 = P;
+    for (int kd = 0; kd < 3; kd++) {
+        float acc[9][8];
+#pragma unroll
+        for (int a = 0; a < 9; a++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[a][j] = 0.f;
+        for (int64_t p = p0 + lane; p < p1; p += 64) {
+            const int ow = (int)(p % g.Wo);
+            int64_t t = p / g.Wo;
+            const int oh = (int)(t % g.Ho);
+            t /= g.Ho;
+            const int od = (int)(t % g.Do);
+            const int n = (int)(t / g.Do);
+            const int id = od + kd - 1;
+            if (id < 0 || id >= g.Di) continue;
+            float dv[8];
+            load_vec<T, 8>(dy + p * g.lddy + co0, dv);
+#pragma unroll
+            for (int kh = 0; kh < 3; kh++) {
+                const int ih = oh + kh - 1;
+                if (ih < 0 || ih >= g.Hi) continue;
+                const T* row = x + (((int64_t)n * g.Di + id) * g.Hi + ih) * g.Wi * g.ldx;
+#pragma unroll
+                for (int kw = 0; kw < 3; kw++) {
+                    const int iw = ow + kw - 1;
+                    if (iw < 0 || iw >= g.Wi) continue;
+                    const float xv = to_f32<T>(row[(int64_t)iw * g.ldx]);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[kh * 3 + kw][j] = fmaf(xv, dv[j], acc[kh * 3 + kw][j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 9; a++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float s = wave_sum(acc[a][j]);
+                if (lane == 0) part[((int64_t)blockIdx.x * 27 + kd * 9 + a) * g.Cout + co0 + j] = s;
+            }
+    }
+}
+
+bool stem_wgrad_eligible(const WgradGeom& g) {
+    return g.Cin == 1 && g.k == 3 && g.stride == 1 && (g.Cout % 32) == 0 && (g.lddy % 8) == 0;
+}
+
+static int stem_chunks(const WgradGeom& g) {
+    const int64_t P = (int64_t)g.N * g.Do * g.Ho * g.Wo;
+    return (int)((P + STEM_CHUNK - 1) / STEM_CHUNK);
+}
+
+size_t stem_wgrad_ws_bytes(const WgradGeom& g) { return (size_t)stem_chunks(g) * 27 * g.Cout * sizeof(float); }
+
+int stem_wgrad_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, const WgradGeom& g,
+                      int dtype, hipStream_t st) {
+    if (!ws || ws_bytes < stem_wgrad_ws_bytes(g)) return ru3d_fail(-1, "stem_wgrad: workspace too small");
+    const int chunks = stem_chunks(g);
+    dim3 grid(chunks, g.Cout / 32);
+    if (dtype == RU3D_F32)
+        hipLaunchKernelGGL(stem_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (const float*)dy,
+                           (float*)ws, g);
+    else
+        hipLaunchKernelGGL(stem_wgrad_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (const bf16*)dy,
+                           (float*)ws, g);
+    int rc = ru3d_check_launch("stem_wgrad");
+    if (rc) return rc;
+    return wgrad_reduce_launch((const float*)ws, dw, chunks, 27, 1, g.Cout, g.s_o, g.s_i, st);
+}
+
+// --------------------------------------------------------------------------- head weight gradient (k1, Cout <= 4)
+// dW[co][ci] = sum_pos x[pos][ci] * dy[pos][co]: thread = (position lane, group of VEC input channels), 16-byte
+// x loads, the 2..4 dy values of a position are shared by the channel-group lanes.
+#define HEAD_SPAN 4096
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                         float* __restrict__ part, WgradGeom g) {
+    __shared__ float sh[256][VEC * 4 + 1];
+    const int G = g.Cin / VEC;          // channel groups (<= 256)
+    const int vpb = 256 / G;
+    const int tid = threadIdx.x;
+    const int cg = tid % G, vl = tid / G;
+    const bool active = vl < vpb;
+    const int64_t P = (int64_t)g.N * g.Do * g.Ho * g.Wo;
+    const int64_t p0 = (int64_t)blockIdx.x * HEAD_SPAN;
+    int64_t p1 = p0 + HEAD_SPAN;
+    if (p1 > P) p1 = P;
+    float acc[VEC][4];
+#pragma unroll
+    for (int i = 0; i < VEC; i++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[i][c] = 0.f;
+    if (active) {
+        for (int64_t p = p0 + vl; p < p1; p += vpb) {
+            float xv[VEC], dv[4];
+            load_vec<T, VEC>(x + p * g.ldx + cg * VEC, xv);
+#pragma unroll
+            for (int c = 0; c < 4; c++) dv[c] = c < g.Cout ? to_f32<T>(dy[p * g.lddy + c]) : 0.f;
+#pragma unroll
+            for (int i = 0; i < VEC; i++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[i][c] = fmaf(xv[i], dv[c], acc[i][c]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VEC; i++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) sh[tid][i * 4 + c] = active ? acc[i][c] : 0.f;
+    __syncthreads();
+    if (vl == 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; i++)
+            for (int c = 0; c < g.Cout; c++) {
+                float s = 0.f;
+                for (int l = 0; l < vpb; l++) s += sh[l * G + cg][i * 4 + c];
+                // slab layout [chunk][tap = 0][ci][co]
+                part[((int64_t)blockIdx.x * g.Cin + cg * VEC + i) * g.Cout + c] = s;
+            }
+    }
+}
+
+bool head_wgrad_eligible(const WgradGeom& g, int dtype) {
+    const int vec = dtype == RU3D_BF16 ? 8 : 4;
+    return g.k == 1 && g.stride == 1 && g.Cout <= 4 && (g.Cin % vec) == 0 && (g.Cin / vec) <= 256 &&
+           (g.ldx % vec) == 0;
+}
+
+static int head_chunks(const WgradGeom& g) {
+    const int64_t P = (int64_t)g.N * g.Do * g.Ho * g.Wo;
+    return (int)((P + HEAD_SPAN - 1) / HEAD_SPAN);
+}
+
+size_t head_wgrad_ws_bytes(const WgradGeom& g) { return (size_t)head_chunks(g) * g.Cin * g.Cout * sizeof(float); }
+
+int head_wgrad_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, const WgradGeom& g,
+                      int dtype, hipStream_t st) {
+    if (!ws || ws_bytes < head_wgrad_ws_bytes(g)) return ru3d_fail(-1, "head_wgrad: workspace too small");
+    if (((uintptr_t)x) % 16) return ru3d_fail(-1, "head_wgrad: x must be 16-byte aligned");
+    const int chunks = head_chunks(g);
+    if (dtype == RU3D_F32)
+        hipLaunchKernelGGL((head_wgrad_kernel<float, 4>), dim3(chunks), dim3(256), 0, st, (const float*)x,
+                           (const float*)dy, (float*)ws, g);
+    else
+        hipLaunchKernelGGL((head_wgrad_kernel<bf16, 8>), dim3(chunks), dim3(256), 0, st, (const bf16*)x,
+                           (const bf16*)dy, (float*)ws, g);
+    int rc = ru3d_check_launch("head_wgrad");
+    if (rc) return rc;
+    return wgrad_reduce_launch((const float*)ws, dw, chunks, 1, g.Cin, g.Cout, g.s_o, g.s_i, st);
+}
