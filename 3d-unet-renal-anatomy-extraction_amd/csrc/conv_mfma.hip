@@ -75,11 +75,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
-template <int TD, int TH, int TW, int NT>
+// MT = MFMA column tiles (32 voxels) per wave: 2 for the large levels (256-voxel tile), 1 for the deep,
+// spatially small levels where more, smaller workgroups are needed to fill 256 CUs.
+// WD = depth (in (tap, k-step) steps) of the register ring that prefetches weight fragments: the loads of step
+// s + WD are issued right after the MFMAs of step s, so ~WD*MT*NT MFMAs (>= 500 cycles) cover an L2 hit.
+template <int TD, int TH, int TW, int MT, int NT>
 __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
     constexpr int HD = TD + 2, HH = TH + 2, WW = TW + 2;
     constexpr int HV = HD * HH * WW;
-    static_assert(TD * TH * TW == 256, "tile must hold 256 voxels");
+    constexpr int WD = (MT * NT >= 4) ? 4 : 8;
+    constexpr int S = 54;   // 27 taps x 2 k-steps per 32-channel chunk
+    static_assert(TD * TH * TW == 128 * MT, "tile must hold 128*MT voxels");
     static_assert(HV * MF_PITCH * 2 <= 65536, "halo tile must leave room for 2 workgroups per CU");
     __shared__ __attribute__((aligned(16))) bf16 lds[HV * MF_PITCH];
 
@@ -95,11 +101,11 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
     const int co_blk = blockIdx.y * (NT * 32);
     const int NTT = a.Cout / 32, KS = a.Cin / 16;
 
-    // this lane's two output voxels (one per MFMA column tile owned by the wave)
-    int hv0[2], od[2], oh[2], ow[2];
+    // this lane's output voxels (one per MFMA column tile owned by the wave)
+    int hv0[MT], od[MT], oh[MT], ow[MT];
 #pragma unroll
-    for (int m = 0; m < 2; m++) {
-        const int f = (wave * 2 + m) * 32 + (lane & 31);
+    for (int m = 0; m < MT; m++) {
+        const int f = (wave * MT + m) * 32 + (lane & 31);
         const int tdl = f / (TH * TW), thl = (f / TW) % TH, twl = f % TW;
         od[m] = d0 + tdl;
         oh[m] = h0 + thl;
@@ -107,56 +113,75 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
         hv0[m] = ((tdl * HH + thl) * WW + twl) * MF_PITCH + (lane >> 5) * 8;  // + k-half of the fragment
     }
 
-    f32x16 acc[2][NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int m = 0; m < 2; m++)
+    for (int m = 0; m < MT; m++)
 #pragma unroll
         for (int t = 0; t < NT; t++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[m][t][i] = 0.f;
 
+    const bf16x8* wbase = a.w + (int64_t)blockIdx.y * NT * 64 + lane;
     const int nchunks = a.Cin / 32;
     for (int ch = 0; ch < nchunks; ch++) {
-        if (ch) __syncthreads();  // everyone done reading the previous chunk
-        // ---- stage the halo tile of channels [32 ch, 32 ch + 32): 4 x 16-byte pieces per voxel
-        for (int c = tid; c < HV * 4; c += 256) {
+        // ---- weight ring prologue (independent of LDS: its latency hides under the staging below)
+        bf16x8 wq[WD][NT];
+#pragma unroll
+        for (int s = 0; s < WD; s++) {
+            const int tap = s >> 1, kc = s & 1;
+            const int wtap = a.flip ? 26 - tap : tap;
+#pragma unroll
+            for (int t = 0; t < NT; t++) wq[s][t] = wbase[((int64_t)(wtap * KS + ch * 2 + kc) * NTT + t) * 64];
+        }
+        // ---- stage the halo tile of channels [32 ch, 32 ch + 32): all loads first, then all LDS writes
+        constexpr int NIT = (HV * 4 + 255) / 256;
+        bf16x8 stage[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; i++) {
+            const int c = tid + i * 256;
             const int hv = c >> 2, part = c & 3;
             const int zw = hv % WW, zh = (hv / WW) % HH, zd = hv / (WW * HH);
             const int gd = d0 + zd - 1, gh = h0 + zh - 1, gw = w0 + zw - 1;
             bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)
+            if (c < HV * 4 && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)
                 v = *reinterpret_cast<const bf16x8*>(a.x + ((((int64_t)n * a.D + gd) * a.H + gh) * a.W + gw) * a.ldx +
                                                      ch * 32 + part * 8);
-            *reinterpret_cast<bf16x8*>(&lds[hv * MF_PITCH + part * 8]) = v;
+            stage[i] = v;
+        }
+        if (ch) __syncthreads();  // everyone done reading the previous chunk
+#pragma unroll
+        for (int i = 0; i < NIT; i++) {
+            const int c = tid + i * 256;
+            if (c < HV * 4) *reinterpret_cast<bf16x8*>(&lds[(c >> 2) * MF_PITCH + (c & 3) * 8]) = stage[i];
         }
         __syncthreads();
         // ---- 27 taps x 2 k-steps of 16 channels
 #pragma unroll
-        for (int tap = 0; tap < 27; tap++) {
+        for (int s = 0; s < S; s++) {
+            const int tap = s >> 1, kc = s & 1;
             const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
             const int toff = ((kd * HH + kh) * WW + kw) * MF_PITCH;
-            const int wtap = a.flip ? 26 - tap : tap;
+            bf16x8 xb[MT];
 #pragma unroll
-            for (int kc = 0; kc < 2; kc++) {
-                bf16x8 xb[2];
+            for (int m = 0; m < MT; m++) xb[m] = *reinterpret_cast<const bf16x8*>(&lds[hv0[m] + toff + kc * 16]);
 #pragma unroll
-                for (int m = 0; m < 2; m++)
-                    xb[m] = *reinterpret_cast<const bf16x8*>(&lds[hv0[m] + toff + kc * 16]);
-                const bf16x8* wrow = a.w + ((int64_t)(wtap * KS + ch * 2 + kc) * NTT + blockIdx.y * NT) * 64 + lane;
+            for (int t = 0; t < NT; t++)
 #pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    const bf16x8 wa = wrow[t * 64];
+                for (int m = 0; m < MT; m++)
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s % WD][t], xb[m], acc[m][t], 0, 0, 0);
+            if (s + WD < S) {
+                const int tap2 = (s + WD) >> 1, kc2 = (s + WD) & 1;
+                const int wtap2 = a.flip ? 26 - tap2 : tap2;
 #pragma unroll
-                    for (int m = 0; m < 2; m++)
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb[m], acc[m][t], 0, 0, 0);
-                }
+                for (int t = 0; t < NT; t++)
+                    wq[s % WD][t] = wbase[((int64_t)(wtap2 * KS + ch * 2 + kc2) * NTT + t) * 64];
             }
         }
     }
 
     // ---- epilogue: lane = voxel, 16 couts per accumulator in 4 groups of 4 consecutive channels
 #pragma unroll
-    for (int m = 0; m < 2; m++) {
+    for (int m = 0; m < MT; m++) {
         if (od[m] >= a.D || oh[m] >= a.H || ow[m] >= a.W) continue;
         const int64_t vox = (((int64_t)n * a.D + od[m]) * a.H + oh[m]) * a.W + ow[m];
 #pragma unroll
@@ -184,8 +209,8 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
     }
 }
 
-template <int TD, int TH, int TW>
-static int launch_s1(const MfmaConvArgs& a0, hipStream_t st) {
+template <int TD, int TH, int TW, int MT>
+static int launch_s1(const MfmaConvArgs& a0, bool nt2, hipStream_t st) {
     MfmaConvArgs a = a0;
     a.tiles_d = (a.D + TD - 1) / TD;
     a.tiles_h = (a.H + TH - 1) / TH;
@@ -193,14 +218,37 @@ static int launch_s1(const MfmaConvArgs& a0, hipStream_t st) {
     const int64_t nblk = (int64_t)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
     if (nblk > 0x7fffffff) return ru3d_fail(-1, "conv_mfma: grid too large");
     a.nblk = (int)nblk;
-    if (a.Cout % 64 == 0) {
+    if (nt2) {
         dim3 grid((unsigned)nblk, a.Cout / 64);
-        hipLaunchKernelGGL((conv3_s1_mfma_kernel<TD, TH, TW, 2>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv3_s1_mfma_kernel<TD, TH, TW, MT, 2>), grid, dim3(256), 0, st, a);
     } else {
         dim3 grid((unsigned)nblk, a.Cout / 32);
-        hipLaunchKernelGGL((conv3_s1_mfma_kernel<TD, TH, TW, 1>), grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL((conv3_s1_mfma_kernel<TD, TH, TW, MT, 1>), grid, dim3(256), 0, st, a);
     }
     return ru3d_check_launch("conv3_s1_mfma");
+}
+
+// Tile choice: W decides the tile's aspect; if the 256-voxel x 64-cout decomposition yields fewer than ~2
+// workgroups per CU (deep levels: 16^3, 8^3), fall back to 128-voxel tiles and then to 32-cout slices.
+static int launch_s1_auto(const MfmaConvArgs& a, hipStream_t st) {
+    auto cdiv = [](int x, int y) { return (x + y - 1) / y; };
+    const bool can_nt2 = (a.Cout % 64) == 0;
+    const int wclass = a.W >= 24 ? 32 : (a.W >= 12 ? 16 : 8);
+    int64_t big;   // workgroups with MT = 2, widest cout slice
+    if (wclass == 32) big = (int64_t)a.N * cdiv(a.D, 2) * cdiv(a.H, 4) * cdiv(a.W, 32);
+    else if (wclass == 16) big = (int64_t)a.N * cdiv(a.D, 2) * cdiv(a.H, 8) * cdiv(a.W, 16);
+    else big = (int64_t)a.N * cdiv(a.D, 4) * cdiv(a.H, 8) * cdiv(a.W, 8);
+    big *= a.Cout / (can_nt2 ? 64 : 32);
+    const bool small = big < 512;
+    const bool nt2 = can_nt2 && (!small || big * 2 >= 1024);
+    if (!small) {
+        if (wclass == 32) return launch_s1<2, 4, 32, 2>(a, nt2, st);
+        if (wclass == 16) return launch_s1<2, 8, 16, 2>(a, nt2, st);
+        return launch_s1<4, 8, 8, 2>(a, nt2, st);
+    }
+    if (wclass == 32) return launch_s1<1, 4, 32, 1>(a, nt2, st);
+    if (wclass == 16) return launch_s1<1, 8, 16, 1>(a, nt2, st);
+    return launch_s1<2, 8, 8, 1>(a, nt2, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -415,9 +463,7 @@ int conv_mfma_launch(const void* x, const void* w, const float* bias, const void
     a.N = g.N; a.D = g.Do; a.H = g.Ho; a.W = g.Wo;
     a.Cin = g.Cin; a.Cout = g.Cout; a.ldx = g.ldx; a.ldy = g.ldy; a.ldr = g.ldr;
     a.flip = g.flip;
-    if (g.Wo >= 24) return launch_s1<2, 4, 32>(a, st);
-    if (g.Wo >= 12) return launch_s1<2, 8, 16>(a, st);
-    return launch_s1<4, 8, 8>(a, st);
+    return launch_s1_auto(a, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -490,25 +536,42 @@ __global__ __launch_bounds__(256, 2) void wgrad3_s1_mfma_kernel(MfmaWgradArgs a)
         tt /= a.tiles_h;
         const int d0 = (tt % a.tiles_d) * TD;
         const int n = tt / a.tiles_d;
-        __syncthreads();   // previous tile fully consumed
-        for (int c = tid; c < HV * 4; c += 256) {
+        // all global loads first (kept in registers), then the LDS writes: one exposed memory latency per tile
+        constexpr int NIT = (HV * 4 + 255) / 256;
+        bf16x8 sx[NIT], sd[4];
+#pragma unroll
+        for (int i = 0; i < NIT; i++) {
+            const int c = tid + i * 256;
             const int hv = c >> 2, part = c & 3;
             const int zw = hv % WW, zh = (hv / WW) % HH, zd = hv / (WW * HH);
             const int gd = d0 + zd - 1, gh = h0 + zh - 1, gw = w0 + zw - 1;
             bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)
+            if (c < HV * 4 && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)
                 v = *reinterpret_cast<const bf16x8*>(a.x + ((((int64_t)n * a.D + gd) * a.H + gh) * a.W + gw) * a.ldx +
                                                      cit * 32 + part * 8);
-            *reinterpret_cast<bf16x8*>(&xs[hv * 32 + part * 8]) = v;
+            sx[i] = v;
         }
-        for (int c = tid; c < 256 * 4; c += 256) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int c = tid + i * 256;
             const int f = c >> 2, part = c & 3;
             const int gd = d0 + f / (TH * TW), gh = h0 + (f / TW) % TH, gw = w0 + f % TW;
             bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (gd < a.D && gh < a.H && gw < a.W)
                 v = *reinterpret_cast<const bf16x8*>(a.dy + ((((int64_t)n * a.D + gd) * a.H + gh) * a.W + gw) * a.lddy +
                                                      cot * 32 + part * 8);
-            *reinterpret_cast<bf16x8*>(&ds[f * 32 + part * 8]) = v;
+            sd[i] = v;
+        }
+        __syncthreads();   // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < NIT; i++) {
+            const int c = tid + i * 256;
+            if (c < HV * 4) *reinterpret_cast<bf16x8*>(&xs[(c >> 2) * 32 + (c & 3) * 8]) = sx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int c = tid + i * 256;
+            *reinterpret_cast<bf16x8*>(&ds[(c >> 2) * 32 + (c & 3) * 8]) = sd[i];
         }
         __syncthreads();
 #pragma unroll
