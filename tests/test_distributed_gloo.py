@@ -1,0 +1,148 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel gradient exchange (parallel.GradSync): bucketed,
+asynchronous all-reduce in autograd order; averaged gradient == mean over ranks of the per-shard
+gradients; parameters without a gradient are skipped identically on every rank; the Trainer uses it
+when torch.distributed is initialised."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "3d-unet-renal-anatomy-extraction_amd")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class _Net(torch.nn.Module):
+    """Small conv net with an always-constructed-but-unused branch, like ResBlock.skip_conv."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Conv3d(1, 4, 3, padding=1)
+        self.b = torch.nn.Conv3d(4, 4, 3, padding=1)
+        self.unused = torch.nn.Conv3d(4, 4, 1)
+        self.c = torch.nn.Conv3d(4, 2, 1)
+
+    def forward(self, x):
+        return self.c(torch.relu(self.b(torch.relu(self.a(x)))))
+
+
+def _data(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return torch.randn(2, 1, 6, 6, 6, generator=g), torch.randint(0, 2, (2, 6, 6, 6), generator=g)
+
+
+def _worker(rank, world, port, bucket_bytes, out):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from parallel import GradSync, broadcast_parameters
+        torch.manual_seed(rank)            # different init per rank: broadcast must fix it
+        model = _Net()
+        broadcast_parameters(model)
+        sync = GradSync(model, bucket_bytes=bucket_bytes)
+        x, y = _data(rank)
+        for step in range(2):              # second step re-uses the flat buckets
+            model.zero_grad(set_to_none=True)
+            sync.begin_step()
+            torch.nn.functional.cross_entropy(model(x), y).backward()
+            sync.finish_step()
+        grads = {k: (None if p.grad is None else p.grad.clone()) for k, p in model.named_parameters()}
+        weights = {k: p.detach().clone() for k, p in model.named_parameters()}
+        torch.save({"grads": grads, "weights": weights, "buckets": len(sync._buckets)},
+                   os.path.join(out, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_bytes", [64 << 20, 512])   # one big bucket / many small ones
+def test_gradsync_world2_matches_mean_of_shard_gradients(tmp_path, bucket_bytes):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), bucket_bytes, str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(world)]
+    # identical weights after broadcast, identical averaged gradients on both ranks
+    for k in res[0]["weights"]:
+        assert torch.equal(res[0]["weights"][k], res[1]["weights"][k]), k
+        g0, g1 = res[0]["grads"][k], res[1]["grads"][k]
+        assert (g0 is None) == (g1 is None)
+        if g0 is not None:
+            assert torch.equal(g0, g1), k
+    assert res[0]["grads"]["unused.weight"] is None and res[0]["grads"]["unused.bias"] is None
+    if bucket_bytes == 512:
+        assert res[0]["buckets"] > 1
+    # reference: single process, same weights, mean of the two shard gradients
+    model = _Net()
+    model.load_state_dict(res[0]["weights"])
+    shard = []
+    for r in range(world):
+        model.zero_grad(set_to_none=True)
+        x, y = _data(r)
+        torch.nn.functional.cross_entropy(model(x), y).backward()
+        shard.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    for k, g in res[0]["grads"].items():
+        if g is None:
+            continue
+        ref = (shard[0][k] + shard[1][k]) / 2
+        assert torch.allclose(g, ref, rtol=1e-5, atol=1e-7), k
+
+
+def _trainer_worker(rank, world, port, out):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        import trainer as T
+        from parallel import broadcast_parameters
+
+        class Data(torch.utils.data.Dataset):
+            def __len__(self):
+                return 4
+
+            def __getitem__(self, i):
+                x, y = _data(10 * rank + i)
+                return {"image": x[0], "label": y[0]}
+
+        class Loss(torch.nn.Module):
+            def forward(self, p, t):
+                return torch.nn.functional.cross_entropy(p, t)
+
+        torch.manual_seed(0)
+        np.random.seed(0)
+        model = _Net()
+        broadcast_parameters(model)
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)
+        tr = T.Trainer(model=model, optimizer=opt, loss=Loss(), dataset=Data(), batch_size=2, valid_split=0.0,
+                       dataloader_kwargs={"num_workers": 0}, progress=False)
+        tr.fit(num_epochs=1, save_dir=os.path.join(out, "ckpt"))
+        assert tr._grad_sync is not None
+        torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(out, "w%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_uses_gradsync_and_keeps_ranks_in_lockstep(tmp_path):
+    world = 2
+    mp.spawn(_trainer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    w0 = torch.load(os.path.join(str(tmp_path), "w0.pt"), weights_only=False)
+    w1 = torch.load(os.path.join(str(tmp_path), "w1.pt"), weights_only=False)
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k     # different data per rank, identical weights after training
+    assert os.path.exists(os.path.join(str(tmp_path), "ckpt-last.pt"))   # rank 0 wrote the checkpoint
