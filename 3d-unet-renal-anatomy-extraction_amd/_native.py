@@ -25,6 +25,13 @@ class Tensor(ctypes.Structure):
                 ("w", ctypes.c_int32), ("c", ctypes.c_int32), ("ld", ctypes.c_int32)]
 
 
+class PackItem(ctypes.Structure):
+    """struct ru3d_pack_item"""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("cout", ctypes.c_int32), ("cin", ctypes.c_int32),
+                ("k", ctypes.c_int32), ("stride", ctypes.c_int32), ("role", ctypes.c_int32)]
+
+
+PACK_MAX = 8
 _P = ctypes.POINTER(Tensor)
 _vp, _i, _i64, _f, _sz, _u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t,
                                 ctypes.c_uint64)
@@ -35,6 +42,7 @@ SIGNATURES = {
     "ru3d_last_error": (ctypes.c_char_p, []),
     "ru3d_packed_weight_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "ru3d_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ru3d_pack_weights": (_i, [ctypes.POINTER(PackItem), _i, _i, _vp]),
     "ru3d_conv3d_fwd": (_i, [_P, _vp, _vp, _P, _P, _i, _i, _i, _i, _vp]),
     "ru3d_conv3d_dgrad": (_i, [_P, _vp, _P, _P, _i, _i, _i, _vp]),
     "ru3d_conv3d_wgrad_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),

@@ -37,6 +37,40 @@ def pack_weight(w, role, dtype, stride=1):
     return out
 
 
+def pack_weights(specs, dtype):
+    """specs: list of (weight, role, stride) -> list of packed tensors, produced by ONE kernel launch per
+    RU3D_PACK_MAX weights (the packs share one allocation)."""
+    code = N.dtype_code(dtype)
+    metas, sizes = [], []
+    for w, role, stride in specs:
+        N.require_device(w, "weight")
+        w = w.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            w = w.float().contiguous()
+        k = w.shape[2]
+        if role in (N.ROLE_CONVT_FWD, N.ROLE_CONVT_DGRAD):
+            cin, cout, stride = w.shape[0], w.shape[1], 2
+        else:
+            cout, cin = w.shape[0], w.shape[1]
+        nbytes = N.lib.ru3d_packed_weight_bytes(cout, cin, k, stride, role, code)
+        if nbytes == 0:
+            raise N.Ru3dError("ru3d: cannot pack weight of shape %s" % (tuple(w.shape),))
+        metas.append((w, cout, cin, k, stride, role))
+        sizes.append((nbytes + 255) // 256 * 256)
+    buf = torch.empty(sum(sizes), dtype=torch.uint8, device=specs[0][0].device)
+    outs, off = [], 0
+    for sz in sizes:
+        outs.append(buf[off:off + sz])
+        off += sz
+    for i0 in range(0, len(metas), N.PACK_MAX):
+        chunk = metas[i0:i0 + N.PACK_MAX]
+        items = (N.PackItem * len(chunk))()
+        for j, (w, cout, cin, k, stride, role) in enumerate(chunk):
+            items[j] = N.PackItem(w.data_ptr(), outs[i0 + j].data_ptr(), cout, cin, k, stride, role)
+        check(N.lib.ru3d_pack_weights(items, len(chunk), code, stream()), "pack_weights")
+    return outs
+
+
 def _bias(b):
     if b is None:
         return None
@@ -293,9 +327,13 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, storage_dtype, out_dtype):
         xin = as_input(x, storage_dtype)
         k = weight.shape[2]
-        pw = pack_weight(weight, N.ROLE_CONV_FWD, storage_dtype, stride)
-        y = conv_fwd(xin, pw, bias, weight.shape[0], k, stride, out_dtype=out_dtype)
-        ctx.save_for_backward(xin, weight)
+        specs = [(weight, N.ROLE_CONV_FWD, stride)]
+        if ctx.needs_input_grad[0]:
+            specs.append((weight, N.ROLE_CONV_DGRAD, stride))
+        packs = pack_weights(specs, storage_dtype)
+        y = conv_fwd(xin, packs[0], bias, weight.shape[0], k, stride, out_dtype=out_dtype)
+        ctx.save_for_backward(xin, packs[1] if len(packs) > 1 else None)
+        ctx.cout = weight.shape[0]
         ctx.stride, ctx.k, ctx.has_bias = stride, k, bias is not None
         ctx.storage_dtype = storage_dtype
         ctx.in_dtype = x.dtype
@@ -303,7 +341,7 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        xin, weight = ctx.saved_tensors
+        xin, pwd = ctx.saved_tensors
         sd = ctx.storage_dtype
         gy = as_grad(gy, sd)
         gx = gw = gb = None
@@ -312,7 +350,6 @@ class ConvFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = channel_sum(gy)
         if ctx.needs_input_grad[0]:
-            pwd = pack_weight(weight, N.ROLE_CONV_DGRAD, sd, ctx.stride)
             gx = conv_dgrad(gy, pwd, tuple(xin.shape), ctx.k, ctx.stride)
             if gx.dtype != ctx.in_dtype:
                 gx = gx.to(ctx.in_dtype)
@@ -331,39 +368,52 @@ class ResBlockFn(torch.autograd.Function):
         sd = x.dtype
         x = N.to_ndhwc(x)
         cout = w1.shape[0]
-        pw1 = pack_weight(w1, N.ROLE_CONV_FWD, sd, stride)
+        # every packed form this block needs (forward now, input gradients later) in one launch
+        train = any(ctx.needs_input_grad)
+        need_gx = ctx.needs_input_grad[0]
+        specs = [(w1, N.ROLE_CONV_FWD, stride), (w2, N.ROLE_CONV_FWD, 1)]
+        if ws is not None:
+            specs.append((ws, N.ROLE_CONV_FWD, stride))
+        nfwd = len(specs)
+        if train:
+            specs.append((w2, N.ROLE_CONV_DGRAD, 1))
+            if need_gx:
+                specs.append((w1, N.ROLE_CONV_DGRAD, stride))
+                if ws is not None:
+                    specs.append((ws, N.ROLE_CONV_DGRAD, stride))
+        packs = pack_weights(specs, sd)
+        pw1, pw2 = packs[0], packs[1]
         y1 = conv_fwd(x, pw1, b1, cout, 3, stride)
         mean1, scale1 = in_stats(y1, drop_scale)
         a1 = in_lrelu_fwd(y1, mean1, scale1)
-        pw2 = pack_weight(w2, N.ROLE_CONV_FWD, sd)
         y2 = conv_fwd(a1, pw2, b2, cout, 3, 1)
         mean2, scale2 = in_stats(y2)
         if ws is not None:
-            pws = pack_weight(ws, N.ROLE_CONV_FWD, sd, stride)
-            skip = conv_fwd(x, pws, bs, cout, 1, stride)
+            skip = conv_fwd(x, packs[2], bs, cout, 1, stride)
         else:
             skip = x
         z = in_lrelu_fwd(y2, mean2, scale2, res=skip)
-        ctx.save_for_backward(x, y1, a1, y2, z, mean1, scale1, mean2, scale2, w1, w2, ws)
+        bwd = packs[nfwd:] + [None] * 3
+        ctx.save_for_backward(x, y1, a1, y2, z, mean1, scale1, mean2, scale2, bwd[0], bwd[1], bwd[2])
+        ctx.shapes = (tuple(w1.shape), tuple(w2.shape))
         ctx.stride = stride
         ctx.has_skip_conv = ws is not None
         return z
 
     @staticmethod
     def backward(ctx, gz):
-        x, y1, a1, y2, z, mean1, scale1, mean2, scale2, w1, w2, ws = ctx.saved_tensors
+        x, y1, a1, y2, z, mean1, scale1, mean2, scale2, pw2d, pw1d, pwsd = ctx.saved_tensors
         sd = x.dtype
         stride = ctx.stride
         gz = as_grad(gz, sd)
         # lrelu(IN(y2) + skip): dy2 and the pre-activation gradient (= d/dskip)
         dy2, gpre = in_lrelu_bwd(gz, z, y2, mean2, scale2, want_gpre=True)
         gw2 = conv_wgrad(a1, dy2, 3, 1)
-        gb2 = torch.zeros(w2.shape[0], dtype=torch.float32, device=x.device)  # bias before IN: gradient == 0
-        pw2d = pack_weight(w2, N.ROLE_CONV_DGRAD, sd)
+        gb2 = None   # a bias that feeds InstanceNorm has an identically zero gradient: reported as "no gradient"
         da1 = conv_dgrad(dy2, pw2d, tuple(a1.shape), 3, 1)
         dy1, _ = in_lrelu_bwd(da1, a1, y1, mean1, scale1)
         gw1 = conv_wgrad(x, dy1, 3, stride)
-        gb1 = torch.zeros(w1.shape[0], dtype=torch.float32, device=x.device)
+        gb1 = None
         gws = gbs = None
         gx = None
         need_gx = ctx.needs_input_grad[0]
@@ -371,12 +421,9 @@ class ResBlockFn(torch.autograd.Function):
             gws = conv_wgrad(x, gpre, 1, stride)
             gbs = channel_sum(gpre)
             if need_gx:
-                pwsd = pack_weight(ws, N.ROLE_CONV_DGRAD, sd, stride)
                 gx0 = conv_dgrad(gpre, pwsd, tuple(x.shape), 1, stride)
-                pw1d = pack_weight(w1, N.ROLE_CONV_DGRAD, sd, stride)
                 gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gx0)
         elif need_gx:
-            pw1d = pack_weight(w1, N.ROLE_CONV_DGRAD, sd, stride)
             gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gpre)
         return gx, gw1, gb1, gw2, gb2, gws, gbs, None, None
 
@@ -394,8 +441,11 @@ class UpFn(torch.autograd.Function):
         sd = x.dtype
         x = N.to_ndhwc(x)
         cout = wt.shape[1]
-        pw = pack_weight(wt, N.ROLE_CONVT_FWD, sd)
-        y = convt_fwd(x, pw, bt, cout)
+        specs = [(wt, N.ROLE_CONVT_FWD, 2)]
+        if ctx.needs_input_grad[0]:
+            specs.append((wt, N.ROLE_CONVT_DGRAD, 2))
+        packs = pack_weights(specs, sd)
+        y = convt_fwd(x, packs[0], bt, cout)
         mean, scale = in_stats(y)
         n, _, d, h, w = y.shape
         if skip is not None:
@@ -411,14 +461,14 @@ class UpFn(torch.autograd.Function):
         else:
             u = in_lrelu_fwd(y, mean, scale)
             out = u
-        ctx.save_for_backward(x, y, out, mean, scale, wt)
+        ctx.save_for_backward(x, y, out, mean, scale, packs[1] if len(packs) > 1 else None)
         ctx.cout = cout
         ctx.has_skip = skip is not None
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, y, out, mean, scale, wt = ctx.saved_tensors
+        x, y, out, mean, scale, pwd = ctx.saved_tensors
         sd = x.dtype
         g = as_grad(g, sd)
         cout = ctx.cout
@@ -430,6 +480,5 @@ class UpFn(torch.autograd.Function):
         gb = channel_sum(dy)
         gx = None
         if ctx.needs_input_grad[0]:
-            pwd = pack_weight(wt, N.ROLE_CONVT_DGRAD, sd)
             gx = convt_dgrad(dy, pwd, tuple(x.shape))
         return gx, gw, gb, gskip

@@ -81,6 +81,31 @@ extern "C" int ru3d_pack_weight(const float* src, void* dst, int cout, int cin, 
     return pack_generic_launch(src, dst, kin, kout, taps, s_o, s_i, 0, dtype, as_stream(stream));
 }
 
+extern "C" int ru3d_pack_weights(const ru3d_pack_item* items, int count, int dtype, void* stream) {
+    RU3D_REQUIRE(items && count > 0 && count <= RU3D_PACK_MAX, "pack_weights: count must be 1..%d", RU3D_PACK_MAX);
+    RU3D_REQUIRE(dtype_ok(dtype), "pack_weights: bad dtype");
+    PackBatch b;
+    b.count = count;
+    for (int i = 0; i < count; i++) {
+        const ru3d_pack_item& it = items[i];
+        RU3D_REQUIRE(it.src && it.dst && it.cout > 0 && it.cin > 0 && (it.k == 1 || it.k == 3) &&
+                         (it.stride == 1 || it.stride == 2) && it.role >= 0 && it.role <= 3,
+                     "pack_weights: bad item %d", i);
+        const int taps = it.k * it.k * it.k;
+        int kin, kout;
+        int64_t s_o, s_i;
+        role_channels(it.cout, it.cin, it.role, &kin, &kout, &s_o, &s_i, taps);
+        PackOne& p = b.item[i];
+        p.src = it.src;
+        p.dst = it.dst;
+        p.cin = kin; p.cout = kout; p.taps = taps; p.s_o = s_o; p.s_i = s_i;
+        p.mfma = role_uses_mfma(kin, kout, it.k, it.stride, it.role, dtype) ? 1 : 0;
+        p.cout_pad = generic_cout_pad(kout);
+        p.total = p.mfma ? (int64_t)taps * kin * kout : (int64_t)taps * kin * p.cout_pad;
+    }
+    return pack_batch_launch(b, dtype, as_stream(stream));
+}
+
 static int run_conv(const ru3d_tensor* x, const void* w, const float* bias, const ru3d_tensor* res,
                     const ru3d_tensor* y, int k, int stride, int transposed, int flip, int zero_far, int dtype,
                     int y_dtype, hipStream_t st) {

@@ -23,6 +23,19 @@ struct WgradGeom {
     int64_t chunk_len;           // positions per chunk (filled by the launcher)
 };
 
+// batched weight packing (conv_generic.hip): both packed layouts, up to RU3D_PACK_MAX weights per launch
+struct PackOne {
+    const float* src;
+    void* dst;
+    int cin, cout, taps, mfma, cout_pad;
+    int64_t s_o, s_i, total;
+};
+struct PackBatch {
+    int count;
+    PackOne item[RU3D_PACK_MAX];
+};
+int pack_batch_launch(const PackBatch& b, int dtype, hipStream_t st);
+
 // conv_generic.hip
 int generic_cot(int cout);
 int generic_cout_pad(int cout);

@@ -171,6 +171,50 @@ int pack_generic_launch(const float* src, void* dst, int cin, int cout, int taps
     return ru3d_check_launch("pack_generic");
 }
 
+// Batched packing: blockIdx.y selects the weight, both packed layouts are produced by the same kernel
+// (MFMA fragment order: see conv_mfma.hip; generic: [tap][cin][cout_pad]).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_batch_kernel(PackBatch b) {
+    const PackOne& p = b.item[blockIdx.y];
+    T* dst = (T*)p.dst;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (int64_t)gridDim.x * 256) {
+        float v = 0.f;
+        if (p.mfma) {
+            const int KS = p.cin / 16, NTT = p.cout / 32;
+            const int j = (int)(i & 7);
+            const int lane = (int)((i >> 3) & 63);
+            int64_t t = i >> 9;
+            const int nt = (int)(t % NTT);
+            t /= NTT;
+            const int ks = (int)(t % KS);
+            const int tap = (int)(t / KS);
+            const int co = nt * 32 + (lane & 31);
+            const int ci = ks * 16 + 8 * (lane >> 5) + j;
+            v = p.src[co * p.s_o + ci * p.s_i + tap];
+        } else {
+            const int co = (int)(i % p.cout_pad);
+            const int64_t t = i / p.cout_pad;
+            const int ci = (int)(t % p.cin);
+            const int tap = (int)(t / p.cin);
+            if (co < p.cout) v = p.src[co * p.s_o + ci * p.s_i + tap];
+        }
+        dst[i] = from_f32<T>(v);
+    }
+}
+
+int pack_batch_launch(const PackBatch& b, int dtype, hipStream_t st) {
+    int64_t mx = 1;
+    for (int i = 0; i < b.count; i++) mx = b.item[i].total > mx ? b.item[i].total : mx;
+    int64_t blocks = (mx + 1023) / 1024;   // ~4 elements per thread for the largest item
+    if (blocks > 2048) blocks = 2048;
+    dim3 grid((unsigned)blocks, b.count);
+    if (dtype == RU3D_F32)
+        hipLaunchKernelGGL(pack_batch_kernel<float>, grid, dim3(256), 0, st, b);
+    else
+        hipLaunchKernelGGL(pack_batch_kernel<bf16>, grid, dim3(256), 0, st, b);
+    return ru3d_check_launch("pack_batch");
+}
+
 // --------------------------------------------------------------------------- generic wgrad
 // dW[tap][ci][co] = sum_pos x[s*pos + tap - p][ci] * dy[pos][co], pos over N*Do*Ho*Wo.
 // grid = (chunks, taps, ci_tiles*co_tiles); block = 64x64 (ci x co) tile, 16 positions per LDS stage,
@@ -251,34 +295,53 @@ __global__ __launch_bounds__(256) void wgrad_generic_kernel(const T* __restrict_
 }
 
 // dw[co*s_o + ci*s_i + tap] = sum_chunk part[chunk][tap][ci][co]
-// block = 64 consecutive outputs x 4 chunk lanes (coalesced slab reads); the 4 lane sums are combined in a
-// fixed order -> deterministic.  Small chunk counts use 1 lane per output.
+// block = 64 x (4 consecutive outputs, one 16-byte load) x 4 chunk lanes; each lane keeps 4 independent
+// slab loads in flight; the 4 lane sums are combined in a fixed order -> deterministic.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                            int chunks, int taps, int cin, int cout, int64_t s_o,
                                                            int64_t s_i) {
-    __shared__ float sh[4][64];
-    const int64_t total = (int64_t)taps * cin * cout;
+    __shared__ f32x4 sh[4][64];
+    const int64_t total = (int64_t)taps * cin * cout;   // multiple of 4 is NOT required: tail handled scalar
     const int ox = threadIdx.x & 63, ky = threadIdx.x >> 6;
-    const int64_t i = (int64_t)blockIdx.x * 64 + ox;
-    float s = 0.f;
-    if (i < total)
-        for (int c = ky; c < chunks; c += 4) s += part[(int64_t)c * total + i];
+    const int64_t i0 = ((int64_t)blockIdx.x * 64 + ox) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const bool full = (i0 + 3 < total) && ((total & 3) == 0);
+    if (full) {
+        f32x4 s0 = s, s1 = s, s2 = s, s3 = s;
+        int c = ky;
+        for (; c + 12 < chunks; c += 16) {
+            s0 += *reinterpret_cast<const f32x4*>(part + (int64_t)c * total + i0);
+            s1 += *reinterpret_cast<const f32x4*>(part + (int64_t)(c + 4) * total + i0);
+            s2 += *reinterpret_cast<const f32x4*>(part + (int64_t)(c + 8) * total + i0);
+            s3 += *reinterpret_cast<const f32x4*>(part + (int64_t)(c + 12) * total + i0);
+        }
+        for (; c < chunks; c += 4) s0 += *reinterpret_cast<const f32x4*>(part + (int64_t)c * total + i0);
+        s = (s0 + s1) + (s2 + s3);
+    } else {
+        for (int j = 0; j < 4; j++)
+            if (i0 + j < total)
+                for (int c = ky; c < chunks; c += 4) s[j] += part[(int64_t)c * total + i0 + j];
+    }
     sh[ky][ox] = s;
     __syncthreads();
-    if (ky == 0 && i < total) {
+    if (ky == 0) {
         s = (sh[0][ox] + sh[1][ox]) + (sh[2][ox] + sh[3][ox]);
-        const int co = (int)(i % cout);
-        const int64_t t = i / cout;
-        const int ci = (int)(t % cin);
-        const int tap = (int)(t / cin);
-        dw[co * s_o + ci * s_i + tap] = s;
+        for (int j = 0; j < 4; j++) {
+            const int64_t i = i0 + j;
+            if (i >= total) break;
+            const int co = (int)(i % cout);
+            const int64_t t = i / cout;
+            const int ci = (int)(t % cin);
+            const int tap = (int)(t / cin);
+            dw[co * s_o + ci * s_i + tap] = s[j];
+        }
     }
 }
 
 int wgrad_reduce_launch(const float* part, float* dw, int chunks, int taps, int cin, int cout, int64_t s_o, int64_t s_i,
                         hipStream_t st) {
     const int64_t total = (int64_t)taps * cin * cout;
-    const int64_t blocks = (total + 63) / 64;
+    const int64_t blocks = (total + 255) / 256;
     if (blocks > 0x7fffffff) return ru3d_fail(-1, "wgrad_reduce: grid too large");
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, dw, chunks, taps, cin, cout,
                        s_o, s_i);

@@ -155,15 +155,22 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
             if (c < HV * 4) *reinterpret_cast<bf16x8*>(&lds[(c >> 2) * MF_PITCH + (c & 3) * 8]) = stage[i];
         }
         __syncthreads();
-        // ---- 27 taps x 2 k-steps of 16 channels
+        // ---- 27 taps x 2 k-steps of 16 channels.  Software pipeline pinned with sched_barrier: the LDS
+        // fragments of step s+1 and the weight fragments of step s+WD are issued before / right after the
+        // MFMAs of step s (hipcc otherwise sinks every load to just before its use: vmcnt(1) per step).
+        bf16x8 xb[MT];
+#pragma unroll
+        for (int m = 0; m < MT; m++) xb[m] = *reinterpret_cast<const bf16x8*>(&lds[hv0[m]]);
 #pragma unroll
         for (int s = 0; s < S; s++) {
-            const int tap = s >> 1, kc = s & 1;
-            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-            const int toff = ((kd * HH + kh) * WW + kw) * MF_PITCH;
-            bf16x8 xb[MT];
+            bf16x8 xn[MT];
+            if (s + 1 < S) {
+                const int tap1 = (s + 1) >> 1, kc1 = (s + 1) & 1;
+                const int toff1 = (((tap1 / 9) * HH + (tap1 / 3) % 3) * WW + tap1 % 3) * MF_PITCH;
 #pragma unroll
-            for (int m = 0; m < MT; m++) xb[m] = *reinterpret_cast<const bf16x8*>(&lds[hv0[m] + toff + kc * 16]);
+                for (int m = 0; m < MT; m++)
+                    xn[m] = *reinterpret_cast<const bf16x8*>(&lds[hv0[m] + toff1 + kc1 * 16]);
+            }
 #pragma unroll
             for (int t = 0; t < NT; t++)
 #pragma unroll
@@ -175,6 +182,11 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
 #pragma unroll
                 for (int t = 0; t < NT; t++)
                     wq[s % WD][t] = wbase[((int64_t)(wtap2 * KS + ch * 2 + kc2) * NTT + t) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < S) {
+#pragma unroll
+                for (int m = 0; m < MT; m++) xb[m] = xn[m];
             }
         }
     }

@@ -74,6 +74,15 @@ size_t ru3d_packed_weight_bytes(int cout, int cin, int k, int stride, int role, 
 int ru3d_pack_weight(const float* src, void* dst, int cout, int cin, int k, int stride, int role, int dtype,
                      void* stream);
 
+/* Same, for up to RU3D_PACK_MAX weights in ONE launch (a ResBlock's three convs x {forward, dgrad}). */
+#define RU3D_PACK_MAX 8
+typedef struct ru3d_pack_item {
+    const float* src; /* fp32 weight, reference layout                  */
+    void* dst;        /* packed output, ru3d_packed_weight_bytes() long  */
+    int32_t cout, cin, k, stride, role;
+} ru3d_pack_item;
+int ru3d_pack_weights(const ru3d_pack_item* items, int count, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ convolutions ------------ */
 /* nn.Conv3d(k in {1,3}, stride in {1,2}, padding=k/2) forward (network.py:394-395,403,541-547).
  * y = conv(x) + bias (+ res).  bias (fp32 [Cout]) and res may be NULL.  y_dtype may be RU3D_F32

@@ -88,12 +88,12 @@ def test_g3_blocks_fp32(golden_dir, tag):
     gref = _sub(z, tag + "/g/")
     for k, p in mod.named_parameters():
         if k in gref:
-            assert p.grad is not None, k
             if k.endswith(("conv1.bias", "conv2.bias")):
-                # a conv bias that feeds InstanceNorm has an analytically-zero gradient: we write exact
-                # zeros, the reference carries rounding noise of the upstream-gradient sum
-                assert float(p.grad.abs().max()) == 0.0 and float(gref[k].abs().max()) < 1e-3, k
+                # a conv bias that feeds InstanceNorm has an analytically-zero gradient: reported as "no
+                # gradient" (None); the reference carries rounding noise of the upstream-gradient sum
+                assert (p.grad is None or float(p.grad.abs().max()) == 0.0) and float(gref[k].abs().max()) < 1e-3, k
                 continue
+            assert p.grad is not None, k
             _close(p.grad, gref[k], 1e-3, 2e-6, "%s grad %s" % (tag, k))
         else:
             assert p.grad is None, "%s: %s should have no gradient" % (tag, k)
@@ -242,7 +242,7 @@ def test_g1_whole_net_fp32(golden_dir):
         if k in none_keys:
             assert p.grad is None, k
         elif k.endswith(("conv1.bias", "conv2.bias")):
-            assert float(p.grad.abs().max()) == 0.0 and float(g64[k].abs().max()) < 1e-9, k
+            assert (p.grad is None or float(p.grad.abs().max()) == 0.0) and float(g64[k].abs().max()) < 1e-9, k
         else:
             _close(p.grad, gref[k], 1.5e-2, 2e-6, "grad vs golden " + k)
             _close(p.grad, g64[k].float(), 5e-3, 1e-7, "grad vs float64 " + k)
