@@ -411,3 +411,56 @@ extern "C" int ru3d_adam_step(float* param, const float* grad, float* exp_avg, f
                        exp_avg_sq, count, lr, beta1, beta2, eps, bias_corr1, sqrtf(bias_corr2), grad_scale);
     return ru3d_check_launch("adam_step");
 }
+
+// multi-tensor form: one launch for the whole model (device-side tensor table + block map)
+__global__ __launch_bounds__(256) void adam_multi_kernel(const ru3d_adam_tensor* __restrict__ tensors,
+                                                         const int32_t* __restrict__ block_map, int chunk_elems,
+                                                         float lr, float b1, float b2, float eps, float bc1,
+                                                         float bc2_sqrt, float gscale) {
+    const ru3d_adam_tensor t = tensors[block_map[2 * blockIdx.x]];
+    if (!t.grad) return;
+    const int64_t begin = (int64_t)block_map[2 * blockIdx.x + 1] * chunk_elems;
+    int64_t end = begin + chunk_elems;
+    if (end > t.count) end = t.count;
+    const float step = lr / bc1;
+    const bool vec = ((((uintptr_t)t.param) | ((uintptr_t)t.grad) | ((uintptr_t)t.exp_avg) | ((uintptr_t)t.exp_avg_sq)) & 15) == 0;
+    int64_t i = begin + (int64_t)threadIdx.x * 4;
+    if (vec) {
+        for (; i + 3 < end; i += 1024) {
+            f32x4 p = *reinterpret_cast<const f32x4*>(t.param + i);
+            const f32x4 g = *reinterpret_cast<const f32x4*>(t.grad + i);
+            f32x4 m = *reinterpret_cast<const f32x4*>(t.exp_avg + i);
+            f32x4 v = *reinterpret_cast<const f32x4*>(t.exp_avg_sq + i);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float gi = g[k] * gscale;
+                m[k] = b1 * m[k] + (1.f - b1) * gi;
+                v[k] = b2 * v[k] + (1.f - b2) * gi * gi;
+                p[k] -= step * (m[k] / (sqrtf(v[k]) / bc2_sqrt + eps));
+            }
+            *reinterpret_cast<f32x4*>(t.param + i) = p;
+            *reinterpret_cast<f32x4*>(t.exp_avg + i) = m;
+            *reinterpret_cast<f32x4*>(t.exp_avg_sq + i) = v;
+        }
+    }
+    // scalar tail (or unaligned tensors): this thread's remaining elements of its 4-wide slots
+    for (; i < end; i += 1024)
+        for (int k = 0; k < 4 && i + k < end; k++) {
+            const float gi = t.grad[i + k] * gscale;
+            const float mi = b1 * t.exp_avg[i + k] + (1.f - b1) * gi;
+            const float vi = b2 * t.exp_avg_sq[i + k] + (1.f - b2) * gi * gi;
+            t.exp_avg[i + k] = mi;
+            t.exp_avg_sq[i + k] = vi;
+            t.param[i + k] -= step * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        }
+}
+
+extern "C" int ru3d_adam_multi(const ru3d_adam_tensor* tensors, const int32_t* block_map, int nblocks, int chunk_elems,
+                               float lr, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
+                               float grad_scale, void* stream) {
+    RU3D_REQUIRE(tensors && block_map && nblocks > 0 && chunk_elems >= 1024 && (chunk_elems % 1024) == 0,
+                 "adam_multi: bad argument (chunk_elems must be a positive multiple of 1024)");
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, as_stream(stream), tensors, block_map,
+                       chunk_elems, lr, beta1, beta2, eps, bias_corr1, sqrtf(bias_corr2), grad_scale);
+    return ru3d_check_launch("adam_multi");
+}

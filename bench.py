@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--pools", type=int, default=4)
     ap.add_argument("--classes", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
+                    help="fused = optim.Adam (ru3d_adam_multi); torch = torch.optim.Adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off")
@@ -102,7 +104,11 @@ def main():
         from parallel import GradSync, broadcast_parameters
         broadcast_parameters(model)
         sync = GradSync(model)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    if args.optimizer == "fused":
+        import optim
+        opt = optim.Adam(model.parameters(), lr=1e-4)      # same update rule, one launch for the whole model
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     wv = [1, 10, 20][:args.classes] if args.classes <= 3 else None
     criterion = loss_mod.HybirdLoss(weight_v=wv)
 

@@ -171,6 +171,20 @@ int ru3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    float lr, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
                    float grad_scale, void* stream);
 
+/* The same update for MANY parameter tensors in one launch.  `tensors` and `block_map` are DEVICE arrays:
+ * block b of the grid updates elements [chunk*chunk_elems, +chunk_elems) of tensors[block_map[2b]] with
+ * chunk = block_map[2b+1].  Tensors whose grad pointer is NULL are skipped (no gradient this step). */
+typedef struct ru3d_adam_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t count;
+} ru3d_adam_tensor;
+int ru3d_adam_multi(const ru3d_adam_tensor* tensors, const int32_t* block_map, int nblocks, int chunk_elems,
+                    float lr, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
+                    float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

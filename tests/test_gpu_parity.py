@@ -273,6 +273,36 @@ def test_g1_adam_three_steps(golden_dir):
             assert d.median().item() <= 1e-5, (k, d.median().item())
 
 
+def test_fused_adam_matches_torch_adam(golden_dir):
+    """optim.Adam (one ru3d_adam_multi launch for the whole model) == torch.optim.Adam, 3 steps, incl. parameters
+    without a gradient and the torch-compatible state_dict layout."""
+    import optim
+    z, model_a = _g1_model(golden_dir)
+    _, model_b = _g1_model(golden_dir)
+    x = torch.from_numpy(z["x"]).to(DEV)
+    y = torch.from_numpy(z["y"].astype(np.int64)).to(DEV)
+    oa = optim.Adam(model_a.parameters(), lr=1e-4)
+    ob = torch.optim.Adam(model_b.parameters(), lr=1e-4)
+    for m in (model_a, model_b):
+        m.eval()
+    for step in range(3):
+        for m, o in ((model_a, oa), (model_b, ob)):
+            o.zero_grad()
+            L.HybirdLoss()(m(x), y).backward()
+            o.step()
+    for (k, pa), (_, pb) in zip(model_a.state_dict().items(), model_b.state_dict().items()):
+        assert (pa - pb).abs().max().item() <= 1e-7, k
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["state"].keys() == sb["state"].keys()
+    for idx in sa["state"]:
+        assert set(sa["state"][idx]) == {"step", "exp_avg", "exp_avg_sq"}
+        assert float(sa["state"][idx]["step"]) == 3.0
+        assert torch.allclose(sa["state"][idx]["exp_avg"], sb["state"][idx]["exp_avg"], rtol=1e-5, atol=1e-12)
+    ob.load_state_dict(sa)      # interchangeable checkpoints
+    with pytest.raises(ValueError):
+        optim.Adam(model_a.parameters(), weight_decay=0.1)
+
+
 def test_g2_dropout_with_injected_masks(golden_dir):
     z1, model = _g1_model(golden_dir)
     z = _load(golden_dir, "g2_dropout.npz")
