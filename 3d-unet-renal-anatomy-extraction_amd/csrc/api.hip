@@ -118,6 +118,8 @@ static int run_conv(const ru3d_tensor* x, const void* w, const float* bias, cons
     g.k = k; g.stride = stride; g.pad = k / 2;
     g.transposed = transposed; g.zero_far = zero_far; g.flip = flip;
     if (stem_fwd_eligible(g, dtype, y_dtype, res)) return stem_fwd_launch(x->ptr, w, bias, y->ptr, g, dtype, st);
+    if (head_fwd_eligible(g, dtype, res)) return head_fwd_launch(x->ptr, w, bias, y->ptr, g, dtype, y_dtype, st);
+    if (!bias && head_dgrad_eligible(g, dtype, y_dtype, res)) return head_dgrad_launch(x->ptr, w, y->ptr, g, dtype, st);
     if (mfma_conv_eligible(g.Cin, g.Cout, k, dtype, y_dtype) && mfma_conv_geometry_ok(g))
         return conv_mfma_launch(x->ptr, w, bias, res ? res->ptr : nullptr, y->ptr, g, st);
     return conv_generic_launch(x->ptr, w, bias, res ? res->ptr : nullptr, y->ptr, g, dtype, y_dtype, st);

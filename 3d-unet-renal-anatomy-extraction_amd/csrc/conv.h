@@ -66,6 +66,11 @@ int wgrad_mfma_launch(const void* x, const void* dy, float* dw, void* ws, size_t
 bool stem_fwd_eligible(const ConvGeom& g, int dtype, int y_dtype, const void* res);
 int stem_fwd_launch(const void* x, const void* w, const float* bias, void* y, const ConvGeom& g, int dtype,
                     hipStream_t st);
+bool head_fwd_eligible(const ConvGeom& g, int dtype, const void* res);
+int head_fwd_launch(const void* x, const void* w, const float* bias, void* y, const ConvGeom& g, int dtype,
+                    int y_dtype, hipStream_t st);
+bool head_dgrad_eligible(const ConvGeom& g, int dtype, int y_dtype, const void* res);
+int head_dgrad_launch(const void* dy, const void* w, void* dx, const ConvGeom& g, int dtype, hipStream_t st);
 bool stem_wgrad_eligible(const WgradGeom& g);
 size_t stem_wgrad_ws_bytes(const WgradGeom& g);
 int stem_wgrad_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, const WgradGeom& g,

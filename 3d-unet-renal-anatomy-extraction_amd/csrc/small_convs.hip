@@ -76,6 +76,115 @@ int stem_fwd_launch(const void* x, const void* w, const float* bias, void* y, co
     return ru3d_check_launch("stem_fwd");
 }
 
+// --------------------------------------------------------------------------- head forward (k1, Cout <= 4)
+// logits[v][co] = b[co] + sum_ci x[v][ci] w[ci][co].  G = Cin/VEC lanes share a voxel: each loads one 16-byte
+// piece (fully coalesced), forms its partial dot products and the G partials are combined by xor-shuffles.
+template <typename T, typename TO, int VEC>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const T* __restrict__ w,
+                                                       const float* __restrict__ bias, TO* __restrict__ y, ConvGeom g) {
+    extern __shared__ float wl[];   // [Cin][4]
+    for (int i = threadIdx.x; i < g.Cin * 4; i += 256) wl[i] = to_f32<T>(w[i]);   // generic packing: [cin][cout_pad = 4]
+    __syncthreads();
+    const int G = g.Cin / VEC;      // power of two, <= 64
+    const int64_t total = (int64_t)g.N * g.Do * g.Ho * g.Wo;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t vo = gid / G;
+    const int cg = (int)(gid % G);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (vo < total) {
+        float xv[VEC];
+        load_vec<T, VEC>(x + vo * g.ldx + cg * VEC, xv);
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+            const float* wr = wl + (cg * VEC + i) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c] = fmaf(xv[i], wr[c], acc[c]);
+        }
+    }
+    for (int o = 1; o < G; o <<= 1) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[c] += __shfl_xor(acc[c], o, 64);
+    }
+    if (vo < total && cg == 0) {
+        for (int c = 0; c < g.Cout; c++) y[vo * g.ldy + c] = from_f32<TO>(acc[c] + (bias ? bias[c] : 0.f));
+    }
+}
+
+bool head_fwd_eligible(const ConvGeom& g, int dtype, const void* res) {
+    const int vec = dtype == RU3D_BF16 ? 8 : 4;
+    const int G = g.Cin / vec;
+    return g.k == 1 && g.stride == 1 && !g.transposed && !g.zero_far && !res && g.Cout <= 4 && (g.Cin % vec) == 0 &&
+           G >= 1 && G <= 64 && (G & (G - 1)) == 0 && (g.ldx % vec) == 0;
+}
+
+int head_fwd_launch(const void* x, const void* w, const float* bias, void* y, const ConvGeom& g, int dtype,
+                    int y_dtype, hipStream_t st) {
+    const int vec = dtype == RU3D_BF16 ? 8 : 4;
+    const int64_t total = (int64_t)g.N * g.Do * g.Ho * g.Wo * (g.Cin / vec);
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffff) return ru3d_fail(-1, "head_fwd: grid too large");
+    if (((uintptr_t)x) % 16) return ru3d_fail(-1, "head_fwd: x must be 16-byte aligned");
+    const size_t lds = (size_t)g.Cin * 4 * sizeof(float);
+    dim3 grid((unsigned)blocks);
+    if (dtype == RU3D_F32 && y_dtype == RU3D_F32)
+        hipLaunchKernelGGL((head_fwd_kernel<float, float, 4>), grid, dim3(256), lds, st, (const float*)x,
+                           (const float*)w, bias, (float*)y, g);
+    else if (dtype == RU3D_BF16 && y_dtype == RU3D_F32)
+        hipLaunchKernelGGL((head_fwd_kernel<bf16, float, 8>), grid, dim3(256), lds, st, (const bf16*)x, (const bf16*)w,
+                           bias, (float*)y, g);
+    else if (dtype == RU3D_BF16 && y_dtype == RU3D_BF16)
+        hipLaunchKernelGGL((head_fwd_kernel<bf16, bf16, 8>), grid, dim3(256), lds, st, (const bf16*)x, (const bf16*)w,
+                           bias, (bf16*)y, g);
+    else
+        return ru3d_fail(-1, "head_fwd: unsupported dtype pair");
+    return ru3d_check_launch("head_fwd");
+}
+
+// --------------------------------------------------------------------------- head input gradient (k1, Cin' <= 4)
+// dx[v][c] = sum_{co<=4} dy[v][co] w[co][c]: thread = (voxel, 8 output channels), one 16-byte store.
+template <typename T>
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const T* __restrict__ dy, const T* __restrict__ w,
+                                                         T* __restrict__ dx, ConvGeom g) {
+    extern __shared__ float wl[];   // [Cin'][Cout']
+    for (int i = threadIdx.x; i < g.Cin * g.Cout; i += 256) wl[i] = to_f32<T>(w[(i / g.Cout) * g.CoutPad + (i % g.Cout)]);
+    __syncthreads();
+    const int groups = g.Cout / 8;
+    const int64_t total = (int64_t)g.N * g.Do * g.Ho * g.Wo * groups;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int cg = (int)(gid % groups);
+    const int64_t vo = gid / groups;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.f;
+    for (int ci = 0; ci < g.Cin; ci++) {
+        const float d = to_f32<T>(dy[vo * g.ldx + ci]);
+        const float* wr = wl + ci * g.Cout + cg * 8;
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = fmaf(d, wr[j], acc[j]);
+    }
+    store_vec<T, 8>(dx + vo * g.ldy + cg * 8, acc);
+}
+
+bool head_dgrad_eligible(const ConvGeom& g, int dtype, int y_dtype, const void* res) {
+    return g.k == 1 && g.stride == 1 && !g.transposed && !g.zero_far && !res && dtype == y_dtype && g.Cin <= 4 &&
+           (g.Cout % 8) == 0 && g.Cout <= 1024 && (g.ldy % 8) == 0;
+}
+
+int head_dgrad_launch(const void* dy, const void* w, void* dx, const ConvGeom& g, int dtype, hipStream_t st) {
+    const int64_t total = (int64_t)g.N * g.Do * g.Ho * g.Wo * (g.Cout / 8);
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffff) return ru3d_fail(-1, "head_dgrad: grid too large");
+    const size_t lds = (size_t)g.Cin * g.Cout * sizeof(float);
+    if (dtype == RU3D_F32)
+        hipLaunchKernelGGL(head_dgrad_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, st, (const float*)dy,
+                           (const float*)w, (float*)dx, g);
+    else
+        hipLaunchKernelGGL(head_dgrad_kernel<bf16>, dim3((unsigned)blocks), dim3(256), lds, st, (const bf16*)dy,
+                           (const bf16*)w, (bf16*)dx, g);
+    return ru3d_check_launch("head_dgrad");
+}
+
 // --------------------------------------------------------------------------- stem weight gradient (Cin == 1)
 // dW[tap][co] = sum_pos x[pos + tap] * dy[pos][co].  Workgroup = a run of STEM_CHUNK flat positions x 32 couts;
 // wave = 8 couts; lanes stride over positions; the three kd planes are processed one after the other so a
@@ -97,13 +206,30 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const T* __restrict__ x
         for (int a = 0; a < 9; a++)
 #pragma unroll
             for (int j = 0; j < 8; j++) acc[a][j] = 0.f;
+        // coordinates of the lane's first position, then advanced by 64 per iteration (no division in the loop)
+        int ow, oh, od, n;
+        {
+            const uint32_t pp = (uint32_t)(p0 + lane);
+            ow = (int)(pp % (uint32_t)g.Wo);
+            uint32_t t = pp / (uint32_t)g.Wo;
+            oh = (int)(t % (uint32_t)g.Ho);
+            t /= (uint32_t)g.Ho;
+            od = (int)(t % (uint32_t)g.Do);
+            n = (int)(t / (uint32_t)g.Do);
+        }
+        ow -= 64;
         for (int64_t p = p0 + lane; p < p1; p += 64) {
-            const int ow = (int)(p % g.Wo);
-            int64_t t = p / g.Wo;
-            const int oh = (int)(t % g.Ho);
-            t /= g.Ho;
-            const int od = (int)(t % g.Do);
-            const int n = (int)(t / g.Do);
+            ow += 64;
+            while (ow >= g.Wo) {
+                ow -= g.Wo;
+                if (++oh == g.Ho) {
+                    oh = 0;
+                    if (++od == g.Do) {
+                        od = 0;
+                        ++n;
+                    }
+                }
+            }
             const int id = od + kd - 1;
             if (id < 0 || id >= g.Di) continue;
             float dv[8];
@@ -134,7 +260,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const T* __restrict__ x
 }
 
 bool stem_wgrad_eligible(const WgradGeom& g) {
-    return g.Cin == 1 && g.k == 3 && g.stride == 1 && (g.Cout % 32) == 0 && (g.lddy % 8) == 0;
+    return g.Cin == 1 && g.k == 3 && g.stride == 1 && (g.Cout % 32) == 0 && (g.lddy % 8) == 0 &&
+           (int64_t)g.N * g.Do * g.Ho * g.Wo < (1ll << 31);
 }
 
 static int stem_chunks(const WgradGeom& g) {
