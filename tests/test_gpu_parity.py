@@ -294,7 +294,7 @@ def test_fused_adam_matches_torch_adam(golden_dir):
             # identical weights + deterministic kernels => identical gradients: the update rule itself must agree
             # to rounding (later steps diverge chaotically on ~0-gradient elements, as with any two Adam builds)
             for (k, pa), (_, pb) in zip(model_a.state_dict().items(), model_b.state_dict().items()):
-                assert (pa - pb).abs().max().item() <= 1e-8, k
+                assert (pa - pb).abs().max().item() <= 6e-8, k      # 1-2 ulp of O(0.3) weights
     for (k, pa), (_, pb) in zip(model_a.state_dict().items(), model_b.state_dict().items()):
         assert (pa - pb).abs().max().item() <= 2.1e-4 * 3, k
         assert (pa - pb).abs().median().item() <= 1e-6, k
