@@ -182,10 +182,21 @@ def main():
             mf = alg_flops / t
             # the 32->32 3x3x3 conv sits at the ridge (AI 432 FLOP/B vs 312): report against HBM, the
             # tighter of the two bounds in bytes for this shape, and carry the MFMA fraction beside it
+            # HBM bytes per launch of this kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
+            # FETCH_SIZE / WRITE_SIZE in separate runs of tools/kbench.py, gfx950 correction applied by
+            # tools/pmc_traffic.py); null when no such measurement exists for this shape.
+            traffic = None
+            key = "conv3d k3 s1 %d->%d on %dx%d^3" % (c, c, args.batch, args.patch)
+            try:
+                pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json"))
+                if pmc and dtype == torch.bfloat16:
+                    traffic = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))[key]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
             out["roofline"] = {"kernel": "conv3d k3 s1 %d->%d on %dx%d^3 (fwd + dgrad launches)" %
                                          (c, c, args.batch, args.patch),
                                "bound": "hbm", "achieved": hbm / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                               "frac": hbm / HBM_PEAK, "traffic": None, "launches": n_launch,
+                               "frac": hbm / HBM_PEAK, "traffic": traffic, "launches": n_launch,
                                "avg_ms": mean_ms, "alg_bytes": alg_bytes,
                                "mfma_tflops": mf / 1e12, "mfma_frac": mf / MFMA_BF16_PEAK}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

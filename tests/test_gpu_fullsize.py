@@ -1,0 +1,149 @@
+"""Full-size (BASELINE.json config 2: 2 x 128^3, F = 32, 4 levels) checks of the HIP path through
+size-independent properties, plus one full-size comparison with the CPU oracle.  `-m gpu` only.
+
+Properties: exact tap-count identities for conv / wgrad on constant inputs (every tile edge of the
+128^3 grid is exercised), linearity under power-of-two scaling (exact in bf16), InstanceNorm moments,
+loss checksums (class probabilities sum to N*V, one-hot counts are exact), determinism of the whole
+training step (fixed-order reductions, no atomics)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("no HIP device", allow_module_level=True)
+
+import _native as N  # noqa: E402
+import _ops as ops  # noqa: E402
+import loss as L  # noqa: E402
+import network  # noqa: E402
+from oracle import unet_oracle as O  # noqa: E402
+
+DEV = torch.device("cuda:0")
+S = 128
+
+
+def _valid_counts(d, h, w):
+    """number of in-range taps of a 3x3x3 / pad-1 stencil at every voxel"""
+    def axis(n):
+        v = torch.full((n,), 3.0)
+        v[0] = v[-1] = 2.0
+        return v
+    return axis(d)[:, None, None] * axis(h)[None, :, None] * axis(w)[None, None, :]
+
+
+def test_conv_and_wgrad_tap_count_identities_full_grid():
+    n, c = 2, 32
+    x = N.new_act(n, c, S, S, S, torch.bfloat16, DEV)
+    x.fill_(1.0)
+    w = torch.full((c, c, 3, 3, 3), 1.0 / c, device=DEV)
+    pw = ops.pack_weight(w, N.ROLE_CONV_FWD, torch.bfloat16, 1)
+    y = ops.conv_fwd(x, pw, None, c, 3, 1)                      # MFMA LDS-halo kernel
+    counts = _valid_counts(S, S, S).to(DEV)
+    assert torch.equal(y.float(), counts[None, None].expand(n, c, S, S, S))
+    # wgrad with x = dy = 1: dW[co][ci][tap] = N * prod_axis (S - |k - 1|), exact in fp32
+    gw = ops.conv_wgrad(x, x, 3, 1)
+    ax = torch.tensor([S - 1.0, S, S - 1.0])
+    expect = n * ax[:, None, None] * ax[None, :, None] * ax[None, None, :]
+    assert torch.equal(gw.cpu(), expect[None, None].expand(c, c, 3, 3, 3))
+    # stride-2 pooling conv (direct MFMA kernel) and its transposed-form input gradient
+    w2 = torch.full((2 * c, c, 3, 3, 3), 1.0 / c, device=DEV)
+    pw2 = ops.pack_weight(w2, N.ROLE_CONV_FWD, torch.bfloat16, 2)
+    y2 = ops.conv_fwd(x, pw2, None, 2 * c, 3, 2)
+    assert tuple(y2.shape) == (n, 2 * c, S // 2, S // 2, S // 2)
+    def axis2(m):
+        v = torch.full((m,), 3.0)
+        v[0] = 2.0            # output o reads inputs 2o-1..2o+1; only o = 0 loses a tap (2*63+1 = 127 is valid)
+        return v
+    c2 = axis2(S // 2)[:, None, None] * axis2(S // 2)[None, :, None] * axis2(S // 2)[None, None, :]
+    assert torch.equal(y2.float(), c2.to(DEV)[None, None].expand(n, 2 * c, S // 2, S // 2, S // 2))
+
+
+def test_linearity_power_of_two_scaling_is_exact():
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn((2, S, S, S, 32), generator=g, device=DEV).bfloat16().permute(0, 4, 1, 2, 3)
+    w = torch.randn((32, 32, 3, 3, 3), generator=g, device=DEV) * 0.05
+    pw = ops.pack_weight(w, N.ROLE_CONV_FWD, torch.bfloat16, 1)
+    y1 = ops.conv_fwd(x, pw, None, 32, 3, 1)
+    y4 = ops.conv_fwd(x * 4, pw, None, 32, 3, 1)
+    assert torch.equal(y4, y1 * 4)
+    assert torch.isfinite(y1).all()
+
+
+def test_instance_norm_moments_full_size():
+    g = torch.Generator(device=DEV).manual_seed(6)
+    y = (torch.randn((2, S, S, S, 32), generator=g, device=DEV) * 3 + 1.5).bfloat16().permute(0, 4, 1, 2, 3)
+    mean, scale = ops.in_stats(y)
+    out = ops.in_lrelu_fwd(y, mean, scale).float()
+    xhat = torch.where(out > 0, out, out / ops.LRELU_SLOPE)
+    m = xhat.mean(dim=(2, 3, 4))
+    v = xhat.var(dim=(2, 3, 4), unbiased=False)
+    assert m.abs().max().item() < 5e-3 and (v - 1).abs().max().item() < 2e-2
+    ref_mean = y.float().mean(dim=(2, 3, 4)).reshape(-1)
+    assert (mean - ref_mean).abs().max().item() < 1e-4
+
+
+def test_loss_checksums_full_size():
+    g = torch.Generator(device=DEV).manual_seed(7)
+    logits = torch.randn((2, S, S, S, 3), generator=g, device=DEV).permute(0, 4, 1, 2, 3).requires_grad_(True)
+    y = torch.randint(0, 3, (2, S, S, S), generator=g, device=DEV)
+    fn = L.HybirdLoss(weight_v=[1, 10, 20])
+    v = fn(logits, y)
+    assert torch.isfinite(v) and v.item() > 0
+    v.backward()
+    gsum = logits.grad.sum(dim=1)           # softmax Jacobian: the class gradients of every voxel sum to 0
+    assert gsum.abs().max().item() < 1e-9
+    # perfect prediction: dice -> 1, focal -> 0
+    onehot = torch.nn.functional.one_hot(y, 3).permute(0, 4, 1, 2, 3).float() * 40.0
+    assert L.HybirdLoss(weight_v=[1, 10, 20])(onehot, y).item() < 1e-5
+    assert abs(L.Dice()(onehot, y).item() - 1.0) < 1e-6
+    # uint8 labels give the same value as int64
+    assert L.HybirdLoss(weight_v=[1, 10, 20])(logits.detach(), y.to(torch.uint8)).item() == pytest.approx(v.item(), abs=0)
+
+
+def _config2(dtype, seed=0):
+    torch.manual_seed(seed)
+    m = network.ResUnet3D(4, 32, 1, 3).to(DEV)
+    network.set_compute_dtype(m, dtype)
+    return m
+
+
+def test_training_step_is_deterministic_bf16():
+    model = _config2(torch.bfloat16).eval()
+    x = O.synth_image((2, 1, S, S, S), 1234).to(DEV)
+    y = torch.randint(0, 3, (2, S, S, S), generator=torch.Generator().manual_seed(1)).to(DEV)
+    runs = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        logits = model(x)
+        loss = L.HybirdLoss(weight_v=[1, 10, 20])(logits, y)
+        loss.backward()
+        runs.append((logits.detach().clone(), loss.item(),
+                     {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+    for k in runs[0][2]:
+        assert torch.equal(runs[0][2][k], runs[1][2][k]), k
+    assert len(runs[0][2]) > 100 and all(torch.isfinite(g).all() for g in runs[0][2].values())
+
+
+def test_config2_forward_fp32_vs_cpu_oracle_full_patch():
+    """ResUnet3D(4,32,1,3) on a full 128^3 patch (N = 1 to keep the CPU side ~10 s), fp32 parity mode vs the
+    CPU oracle on identical weights: logits within 2e-3 abs (5 InstanceNorm-separated levels of fp32 noise),
+    argmax may differ only where the oracle's top-2 margin is below 5e-3, per-class Dice of the masks > 0.999."""
+    model = _config2(torch.float32).eval()
+    w = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    x = O.synth_image((1, 1, S, S, S), 4321)
+    with torch.no_grad():
+        got = model(x.to(DEV)).cpu()
+        torch.set_num_threads(min(16, torch.get_num_threads()))
+        ref = O.unet_forward(x, w, 4)
+    assert (got - ref).abs().max().item() < 2e-3
+    top2 = ref.topk(2, dim=1).values
+    margin = top2[:, 0] - top2[:, 1]
+    flips = got.argmax(1) != ref.argmax(1)
+    assert not (flips & (margin > 5e-3)).any()
+    for c in range(3):
+        a, b = (got.argmax(1) == c).float(), (ref.argmax(1) == c).long()
+        if b.sum() > 0:
+            assert O.tversky(a, b).item() > 0.999
