@@ -132,6 +132,25 @@ def conv_fwd(x, pw, bias, cout, k, stride, res=None, out_dtype=None):
     return y
 
 
+def conv_fwd_in(x, pw, bias, cout, k, stride, drop_scale=None):
+    """conv + InstanceNorm statistics of its output in one entry point (fused in the MFMA epilogue when possible)."""
+    n, _, d, h, w = x.shape
+    y = N.new_act(n, cout, _conv_out(d, k, stride), _conv_out(h, k, stride), _conv_out(w, k, stride), x.dtype, x.device)
+    mean = torch.empty(n * cout, dtype=torch.float32, device=x.device)
+    scale = torch.empty(n * cout, dtype=torch.float32, device=x.device)
+    b = _bias(bias)
+    dx, dyy = desc(x), desc(y)
+    code = N.dtype_code(x.dtype)
+    ws = N.workspace(N.lib.ru3d_conv3d_fwd_in_workspace_bytes(ref(dx), ref(dyy), k, stride, code), x.device)
+    p = _PROBE[0]
+    end = p.begin() if (p is not None and p.match(x.shape[1], cout, k, stride, x.shape[2:])) else None
+    check(N.lib.ru3d_conv3d_fwd_in(ref(dx), ptr(pw), ptr(b), ref(dyy), k, stride, code, ptr(drop_scale), ptr(mean),
+                                   ptr(scale), ptr(ws), ws.numel(), IN_EPS, stream()), "conv3d_fwd_in")
+    if end is not None:
+        end.record()
+    return y, mean, scale
+
+
 def conv_dgrad(dy, pw, in_shape, k, stride, res=None):
     n, cin, d, h, w = in_shape
     dx = N.new_act(n, cin, d, h, w, dy.dtype, dy.device)
@@ -383,11 +402,9 @@ class ResBlockFn(torch.autograd.Function):
                     specs.append((ws, N.ROLE_CONV_DGRAD, stride))
         packs = pack_weights(specs, sd)
         pw1, pw2 = packs[0], packs[1]
-        y1 = conv_fwd(x, pw1, b1, cout, 3, stride)
-        mean1, scale1 = in_stats(y1, drop_scale)
+        y1, mean1, scale1 = conv_fwd_in(x, pw1, b1, cout, 3, stride, drop_scale)
         a1 = in_lrelu_fwd(y1, mean1, scale1)
-        y2 = conv_fwd(a1, pw2, b2, cout, 3, 1)
-        mean2, scale2 = in_stats(y2)
+        y2, mean2, scale2 = conv_fwd_in(a1, pw2, b2, cout, 3, 1)
         if ws is not None:
             skip = conv_fwd(x, packs[2], bs, cout, 1, stride)
         else:

@@ -144,6 +144,54 @@ extern "C" int ru3d_conv3d_fwd(const ru3d_tensor* x, const void* w_packed, const
     return run_conv(x, w_packed, bias, res, y, k, stride, 0, 0, 0, dtype, y_dtype, as_stream(stream));
 }
 
+static ConvGeom fwd_geom(const ru3d_tensor* x, const ru3d_tensor* y, int k, int stride) {
+    ConvGeom g;
+    g.N = x->n;
+    g.Di = x->d; g.Hi = x->h; g.Wi = x->w; g.Cin = x->c; g.ldx = x->ld;
+    g.Do = y->d; g.Ho = y->h; g.Wo = y->w; g.Cout = y->c; g.ldy = y->ld;
+    g.CoutPad = generic_cout_pad(y->c);
+    g.ldr = 0;
+    g.k = k; g.stride = stride; g.pad = k / 2;
+    g.transposed = 0; g.zero_far = 0; g.flip = 0;
+    return g;
+}
+
+static bool fwd_in_fused(const ru3d_tensor* x, const ru3d_tensor* y, int k, int stride, int dtype) {
+    const ConvGeom g = fwd_geom(x, y, k, stride);
+    return mfma_conv_eligible(g.Cin, g.Cout, k, dtype, dtype) && mfma_conv_can_fuse_stats(g);
+}
+
+extern "C" size_t ru3d_conv3d_fwd_in_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* y, int k, int stride,
+                                                     int dtype) {
+    if (!tensor_ok(x) || !tensor_ok(y)) return 0;
+    size_t need = ru3d_reduce_workspace_bytes(y);
+    if (fwd_in_fused(x, y, k, stride, dtype)) {
+        const size_t slab = mfma_conv_stats_slab_bytes(fwd_geom(x, y, k, stride));
+        if (slab > need) need = slab;
+    }
+    return need;
+}
+
+extern "C" int ru3d_conv3d_fwd_in(const ru3d_tensor* x, const void* w_packed, const float* bias, const ru3d_tensor* y,
+                                  int k, int stride, int dtype, const float* drop_scale, float* mean, float* scale,
+                                  void* ws, size_t ws_bytes, float eps, void* stream) {
+    RU3D_REQUIRE(tensor_ok(x) && tensor_ok(y) && w_packed && mean && scale && ws, "conv3d_fwd_in: bad argument");
+    RU3D_REQUIRE(ws_bytes >= ru3d_conv3d_fwd_in_workspace_bytes(x, y, k, stride, dtype), "conv3d_fwd_in: workspace too small");
+    if (fwd_in_fused(x, y, k, stride, dtype)) {
+        RU3D_REQUIRE(x->n == y->n && y->d == x->d && y->h == x->h && y->w == x->w, "conv3d_fwd_in: extents mismatch");
+        const ConvGeom g = fwd_geom(x, y, k, stride);
+        const size_t slab = mfma_conv_stats_slab_bytes(g);
+        hipError_t e = hipMemsetAsync(ws, 0, slab, as_stream(stream));   // workgroups that never touch a sample add 0
+        if (e != hipSuccess) return ru3d_fail((int)e, "conv3d_fwd_in: memset failed: %s", hipGetErrorString(e));
+        int rc = conv_mfma_launch(x->ptr, w_packed, bias, nullptr, y->ptr, g, as_stream(stream), (float*)ws);
+        if (rc) return rc;
+        return mfma_conv_stats_finalize(g, (const float*)ws, drop_scale, eps, mean, scale, as_stream(stream));
+    }
+    int rc = ru3d_conv3d_fwd(x, w_packed, bias, nullptr, y, k, stride, dtype, dtype, stream);
+    if (rc) return rc;
+    return ru3d_instnorm_stats(y, drop_scale, mean, scale, ws, ws_bytes, eps, dtype, stream);
+}
+
 extern "C" int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* res,
                                  const ru3d_tensor* dx, int k, int stride, int dtype, void* stream) {
     RU3D_REQUIRE(tensor_ok(dy) && tensor_ok(dx) && w_packed, "conv3d_dgrad: bad tensor/weight");

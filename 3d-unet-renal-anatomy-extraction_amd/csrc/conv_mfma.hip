@@ -66,6 +66,7 @@ struct MfmaConvArgs {
     int tiles_d, tiles_h, tiles_w;
     int flip;
     int nblk;              // spatial tiles * N (grid.x)
+    float* stat_slab;      // optional: per-(workgroup, wave, n, cout) {sum, sum of squares} of the stored outputs
 };
 
 // T1 (bijective): consecutive hardware block ids round-robin over the 8 XCDs; give each XCD a contiguous
@@ -83,7 +84,8 @@ template <int TD, int TH, int TW, int MT, int NT>
 __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
     constexpr int HD = TD + 2, HH = TH + 2, WW = TW + 2;
     constexpr int HV = HD * HH * WW;
-    constexpr int WD = (MT * NT >= 4) ? 4 : 8;
+    constexpr int WD = (MT * NT >= 4) ? 6 : 12;   // weight-fragment ring depth (steps)
+    constexpr int XD = 3;                          // activation-fragment ring depth (steps)
     constexpr int S = 54;   // 27 taps x 2 k-steps per 32-channel chunk
     static_assert(TD * TH * TW == 128 * MT, "tile must hold 128*MT voxels");
     static_assert(HV * MF_PITCH * 2 <= 65536, "halo tile must leave room for 2 workgroups per CU");
@@ -158,24 +160,30 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
         // ---- 27 taps x 2 k-steps of 16 channels.  Software pipeline pinned with sched_barrier: the LDS
         // fragments of step s+1 and the weight fragments of step s+WD are issued before / right after the
         // MFMAs of step s (hipcc otherwise sinks every load to just before its use: vmcnt(1) per step).
-        bf16x8 xb[MT];
+        // activation fragments: ring of XD steps read ahead from LDS (ds_read_b128 latency under load is
+        // well above one MFMA pair, so a 1-step lookahead still exposes it)
+        bf16x8 xq[XD][MT];
 #pragma unroll
-        for (int m = 0; m < MT; m++) xb[m] = *reinterpret_cast<const bf16x8*>(&lds[hv0[m]]);
+        for (int s = 0; s < XD; s++) {
+            const int tap0 = s >> 1, kc0 = s & 1;
+            const int toff0 = (((tap0 / 9) * HH + (tap0 / 3) % 3) * WW + tap0 % 3) * MF_PITCH;
+#pragma unroll
+            for (int m = 0; m < MT; m++) xq[s][m] = *reinterpret_cast<const bf16x8*>(&lds[hv0[m] + toff0 + kc0 * 16]);
+        }
 #pragma unroll
         for (int s = 0; s < S; s++) {
-            bf16x8 xn[MT];
-            if (s + 1 < S) {
-                const int tap1 = (s + 1) >> 1, kc1 = (s + 1) & 1;
-                const int toff1 = (((tap1 / 9) * HH + (tap1 / 3) % 3) * WW + tap1 % 3) * MF_PITCH;
-#pragma unroll
-                for (int m = 0; m < MT; m++)
-                    xn[m] = *reinterpret_cast<const bf16x8*>(&lds[hv0[m] + toff1 + kc1 * 16]);
-            }
 #pragma unroll
             for (int t = 0; t < NT; t++)
 #pragma unroll
                 for (int m = 0; m < MT; m++)
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s % WD][t], xb[m], acc[m][t], 0, 0, 0);
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s % WD][t], xq[s % XD][m], acc[m][t], 0, 0, 0);
+            if (s + XD < S) {
+                const int tap1 = (s + XD) >> 1, kc1 = (s + XD) & 1;
+                const int toff1 = (((tap1 / 9) * HH + (tap1 / 3) % 3) * WW + tap1 % 3) * MF_PITCH;
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+                    xq[s % XD][m] = *reinterpret_cast<const bf16x8*>(&lds[hv0[m] + toff1 + kc1 * 16]);
+            }
             if (s + WD < S) {
                 const int tap2 = (s + WD) >> 1, kc2 = (s + WD) & 1;
                 const int wtap2 = a.flip ? 26 - tap2 : tap2;
@@ -184,10 +192,6 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
                     wq[s % WD][t] = wbase[((int64_t)(wtap2 * KS + ch * 2 + kc2) * NTT + t) * 64];
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 1 < S) {
-#pragma unroll
-                for (int m = 0; m < MT; m++) xb[m] = xn[m];
-            }
         }
     }
 
@@ -221,6 +225,310 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Producer/consumer form of the same conv for the large levels (>= 2 tiles per CU):
+//   * persistent workgroup of 8 waves, one per CU: waves 0-3 CONSUME (MFMA loop + epilogue, weights through
+//     their own vmcnt-tracked register ring), waves 4-7 PRODUCE (global -> registers -> LDS staging of the
+//     NEXT (tile, 32-channel chunk) item into the other of two LDS halo buffers).  vmcnt is per wave and
+//     in-order, so keeping the long-latency halo loads out of the consumer waves is what lets the weight ring
+//     run with counted waits.  One s_barrier per item hands the buffers over.
+//   * the producers' per-piece global / LDS offsets are tile-invariant and computed once; interior tiles
+//     skip the bounds checks.
+//   * work is dealt XCD-contiguously: the blocks that share an XCD walk a contiguous run of tiles, so the halo
+//     re-reads of neighbouring tiles meet in that XCD's L2.
+// MT = column tiles per consumer wave (tile = 128*MT voxels).  SWZ: unpadded 64-byte voxel pitch with the
+// 16-byte piece index XOR-ed by ((voxel >> 2) & 3) - conflict-free for 32-voxel W runs like the padded layout,
+// but 20 % smaller, which is what lets two 512-voxel halo buffers (MT = 4) fit in 160 KB.  MT = 4 halves the
+// weight-fragment traffic per MFMA (the L1/TA path saturates at 64 B/clk/CU) and the halo amplification.
+template <int TD, int TH, int TW, int MT, int NT, bool SWZ>
+__global__ __launch_bounds__(512, 2) void conv3_s1_pc_kernel(MfmaConvArgs a) {
+    constexpr int PITCH = SWZ ? 32 : MF_PITCH;
+    constexpr int HD = TD + 2, HH = TH + 2, WW = TW + 2;
+    constexpr int HV = HD * HH * WW;
+    // ring depths: ~700 cycles of MFMA work between a weight load and its use, ~2 MFMA groups for LDS reads
+    constexpr int WD = (768 + 32 * MT * NT - 1) / (32 * MT * NT);
+    constexpr int XD = (MT >= 4) ? 2 : 3;
+    constexpr int S = 54;
+    constexpr int NIT = (HV * 4 + 255) / 256;
+    static_assert(TD * TH * TW == 128 * MT, "tile must hold 128*MT voxels");
+    static_assert((2 * HV * PITCH + 4 * MT * 32 * MF_PITCH) * 2 <= 160 * 1024, "two halo buffers must fit in LDS");
+    __shared__ __attribute__((aligned(16))) bf16 lds[2 * HV * PITCH + 4 * MT * 32 * MF_PITCH];   // 2 halo buffers + epilogue patches
+    // element offset of 16-byte piece `p` of halo voxel `hv`
+    auto piece_off = [](int hv, int p) { return SWZ ? hv * 32 + ((p ^ ((hv >> 2) & 3)) << 3) : hv * MF_PITCH + (p << 3); };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= 4;
+    const int NTT = a.Cout / 32, KS = a.Cin / 16;
+    const int nchunks = a.Cin / 32;
+
+    // ---- this workgroup's tiles: XCD-contiguous run, strided by the number of workgroups on that XCD label
+    const int G = gridDim.x, b = blockIdx.x;
+    const int L = G < 8 ? G : 8;                             // XCD labels in use
+    const int xcd = b % L, idx = b / L;
+    const int gx = (G - xcd + L - 1) / L;                    // workgroups with this label
+    const int t_begin = (int)(((int64_t)a.nblk * xcd) / L), t_end = (int)(((int64_t)a.nblk * (xcd + 1)) / L);
+    const int my_tiles = (t_begin + idx < t_end) ? (t_end - t_begin - idx + gx - 1) / gx : 0;
+    const int nitems = my_tiles * nchunks;
+
+    auto tile_origin = [&](int tile, int& n, int& d0, int& h0, int& w0) {
+        const int tw_i = tile % a.tiles_w;
+        tile /= a.tiles_w;
+        const int th_i = tile % a.tiles_h;
+        tile /= a.tiles_h;
+        const int td_i = tile % a.tiles_d;
+        n = tile / a.tiles_d;
+        d0 = td_i * TD;
+        h0 = th_i * TH;
+        w0 = tw_i * TW;
+    };
+
+    if (producer) {
+        // ------------------------------------------------------------------ producer waves
+        const int pt = tid - 256;
+        const int part = pt & 3;                 // c = pt + 256 i: the 16-byte piece index is fixed per thread
+        int rel[NIT], zz[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; i++) {
+            const int c = pt + i * 256;
+            const int hv = (c < HV * 4) ? (c >> 2) : 0;
+            const int zw = hv % WW, zh = (hv / WW) % HH, zd = hv / (WW * HH);
+            rel[i] = ((zd * a.H + zh) * a.W + zw) * a.ldx + part * 8;
+            zz[i] = (c < HV * 4) ? (zd | (zh << 8) | (zw << 16)) : -1;
+        }
+        constexpr int HALF = (NIT + 1) / 2;       // two batches of loads keep the staging registers at 4*HALF
+        for (int it = 0; it <= nitems; it++) {
+            if (it < nitems) {
+                const int tile = t_begin + idx + (it / nchunks) * gx, ch = it % nchunks;
+                int n, d0, h0, w0;
+                tile_origin(tile, n, d0, h0, w0);
+                const bf16* src = a.x + ((((int64_t)n * a.D + (d0 - 1)) * a.H + (h0 - 1)) * a.W + (w0 - 1)) * a.ldx + ch * 32;
+                const bool interior = d0 >= 1 && d0 + TD + 1 <= a.D && h0 >= 1 && h0 + TH + 1 <= a.H && w0 >= 1 &&
+                                      w0 + TW + 1 <= a.W;
+                bf16* dst = lds + (it & 1) * (HV * PITCH);
+#pragma unroll
+                for (int hb = 0; hb < 2; hb++) {
+                    bf16x8 stage[HALF];
+#pragma unroll
+                    for (int j = 0; j < HALF; j++) {
+                        const int i = hb * HALF + j;
+                        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (i < NIT) {
+                            bool ok = zz[i] >= 0;
+                            if (!interior) {
+                                const int gd = d0 - 1 + (zz[i] & 255), gh = h0 - 1 + ((zz[i] >> 8) & 255),
+                                          gw = w0 - 1 + ((zz[i] >> 16) & 255);
+                                ok = ok && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+                            }
+                            if (ok) v = *reinterpret_cast<const bf16x8*>(src + rel[i]);
+                        }
+                        stage[j] = v;
+                    }
+#pragma unroll
+                    for (int j = 0; j < HALF; j++) {
+                        const int i = hb * HALF + j;
+                        if (i < NIT && zz[i] >= 0) {
+                            const int hv = (((zz[i] & 255) * HH) + ((zz[i] >> 8) & 255)) * WW + ((zz[i] >> 16) & 255);
+                            *reinterpret_cast<bf16x8*>(dst + piece_off(hv, part)) = stage[j];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer waves
+    const int co_blk = blockIdx.y * (NT * 32);
+    int hvl[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        const int f = (wave * MT + m) * 32 + (lane & 31);
+        hvl[m] = ((f / (TH * TW)) * HH + (f / TW) % TH) * WW + f % TW;   // halo voxel index of tap (0,0,0)
+    }
+    const bf16x8* wbase = a.w + (int64_t)blockIdx.y * NT * 64 + lane;
+    f32x16 acc[MT][NT];
+    // bias of this lane's 16 couts per cout tile, loaded once (the epilogue must not wait on global loads)
+    f32x4 bq[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            bq[t][q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + co_blk + t * 32 + 8 * q + 4 * (lane >> 5)) : z4;
+        }
+    // fused InstanceNorm statistics: running {sum, sum^2} of this wave's stored values for the sample `cur_n`
+    float st1[NT][8], st2[NT][8];
+    int cur_n = -1;
+    auto stat_flush = [&]() {
+        if (!a.stat_slab || cur_n < 0) return;
+        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+        float* dst = a.stat_slab + ((((int64_t)blk * 4 + wave) * a.N + cur_n) * (NT * 32)) * 2;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                float s1 = st1[t][i], s2 = st2[t][i];
+#pragma unroll
+                for (int o = 4; o < 64; o <<= 1) {   // lanes that share (lane & 3) hold the same 8 channels
+                    s1 += __shfl_xor(s1, o, 64);
+                    s2 += __shfl_xor(s2, o, 64);
+                }
+                if (lane < 4) {
+                    const int c = t * 32 + lane * 8 + i;
+                    dst[c * 2] = s1;
+                    dst[c * 2 + 1] = s2;
+                }
+            }
+    };
+
+    for (int it = 0; it <= nitems; it++) {
+        if (it >= 1) {
+            const int item = it - 1;
+            const int tile = t_begin + idx + (item / nchunks) * gx, ch = item % nchunks;
+            const bf16* buf = lds + (item & 1) * (HV * PITCH);
+            const int ph = lane >> 5;   // k-half of the fragment
+            if (ch == 0) {
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+#pragma unroll
+                    for (int t = 0; t < NT; t++)
+#pragma unroll
+                        for (int i = 0; i < 16; i++) acc[m][t][i] = 0.f;
+            }
+            bf16x8 wq[WD][NT];
+#pragma unroll
+            for (int s = 0; s < WD; s++) {
+                const int tap = s >> 1, kc = s & 1;
+                const int wtap = a.flip ? 26 - tap : tap;
+#pragma unroll
+                for (int t = 0; t < NT; t++) wq[s][t] = wbase[((int64_t)(wtap * KS + ch * 2 + kc) * NTT + t) * 64];
+            }
+            bf16x8 xq[XD][MT];
+#pragma unroll
+            for (int s = 0; s < XD; s++) {
+                const int tap0 = s >> 1, kc0 = s & 1;
+                const int toff0 = ((tap0 / 9) * HH + (tap0 / 3) % 3) * WW + tap0 % 3;
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+                    xq[s][m] = *reinterpret_cast<const bf16x8*>(&buf[piece_off(hvl[m] + toff0, kc0 * 2 + ph)]);
+            }
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int m = 0; m < MT; m++)
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s % WD][t], xq[s % XD][m], acc[m][t], 0, 0, 0);
+                if (s + XD < S) {
+                    const int tap1 = (s + XD) >> 1, kc1 = (s + XD) & 1;
+                    const int toff1 = ((tap1 / 9) * HH + (tap1 / 3) % 3) * WW + tap1 % 3;
+#pragma unroll
+                    for (int m = 0; m < MT; m++)
+                        xq[s % XD][m] = *reinterpret_cast<const bf16x8*>(&buf[piece_off(hvl[m] + toff1, kc1 * 2 + ph)]);
+                }
+                if (s + WD < S) {
+                    const int tap2 = (s + WD) >> 1, kc2 = (s + WD) & 1;
+                    const int wtap2 = a.flip ? 26 - tap2 : tap2;
+#pragma unroll
+                    for (int t = 0; t < NT; t++)
+                        wq[s % WD][t] = wbase[((int64_t)(wtap2 * KS + ch * 2 + kc2) * NTT + t) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ch == nchunks - 1) {
+                // ---- epilogue through a wave-private LDS patch: the accumulator layout (lane = voxel, 4 couts
+                // per 8 bytes) would give 8-byte stores scattered over 32 rows per instruction (store-issue
+                // bound); transposed through LDS every lane stores 16 bytes and a wave-instruction covers 16
+                // whole 64-byte channel rows.  Bias is added before, the residual after the transpose.
+                int n, d0, h0, w0;
+                tile_origin(tile, n, d0, h0, w0);
+                if (a.stat_slab && n != cur_n) {
+                    stat_flush();
+                    cur_n = n;
+#pragma unroll
+                    for (int t = 0; t < NT; t++)
+#pragma unroll
+                        for (int i = 0; i < 8; i++) st1[t][i] = st2[t][i] = 0.f;
+                }
+                bf16* est = lds + 2 * HV * PITCH + wave * (MT * 32 * MF_PITCH);
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+#pragma unroll
+                    for (int m = 0; m < MT; m++) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int cl = 8 * q + 4 * (lane >> 5);
+                            float v[4];
+#pragma unroll
+                            for (int i = 0; i < 4; i++) v[i] = acc[m][t][q * 4 + i];
+#pragma unroll
+                            for (int i = 0; i < 4; i++) v[i] += bq[t][q][i];
+                            store_vec<bf16, 4>(est + (m * 32 + (lane & 31)) * MF_PITCH + cl, v);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 2 * MT; r++) {
+                        const int row = (lane >> 2) + 16 * r, part = lane & 3;
+                        const int f = wave * (MT * 32) + row;
+                        const int od = d0 + f / (TH * TW), oh = h0 + (f / TW) % TH, ow = w0 + f % TW;
+                        float v[8];
+                        load_vec<bf16, 8>(est + row * MF_PITCH + part * 8, v);
+                        if (od < a.D && oh < a.H && ow < a.W) {
+                            const int64_t vox = (((int64_t)n * a.D + od) * a.H + oh) * a.W + ow;
+                            const int c0 = co_blk + t * 32 + part * 8;
+                            if (a.stat_slab) {
+#pragma unroll
+                                for (int i = 0; i < 8; i++) {
+                                    st1[t][i] += v[i];
+                                    st2[t][i] = fmaf(v[i], v[i], st2[t][i]);
+                                }
+                            }
+                            if (a.res) {
+                                float rr[8];
+                                load_vec<bf16, 8>(a.res + vox * a.ldr + c0, rr);
+#pragma unroll
+                                for (int i = 0; i < 8; i++) v[i] += rr[i];
+                            }
+                            store_vec<bf16, 8>(a.y + vox * a.ldy + c0, v);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    stat_flush();
+}
+
+static void pc_grid(int cout, bool nt2, int64_t nblk, int* gx, int* gy) {
+    *gy = cout / (nt2 ? 64 : 32);
+    int g = 256 / *gy;                 // one persistent workgroup per CU in total
+    g = g < 8 ? 8 : (g / 8) * 8;        // multiple of 8 so that blockIdx.x % 8 is the XCD label for every y
+    if (g > nblk) g = (int)nblk;
+    *gx = g;
+}
+
+template <int TD, int TH, int TW, int MT, bool SWZ>
+static int launch_s1_pc(const MfmaConvArgs& a0, bool nt2, hipStream_t st) {
+    MfmaConvArgs a = a0;
+    a.tiles_d = (a.D + TD - 1) / TD;
+    a.tiles_h = (a.H + TH - 1) / TH;
+    a.tiles_w = (a.W + TW - 1) / TW;
+    const int64_t nblk = (int64_t)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
+    if (nblk > 0x7fffffff) return ru3d_fail(-1, "conv_mfma: grid too large");
+    a.nblk = (int)nblk;
+    int gx, gy;
+    pc_grid(a.Cout, nt2, nblk, &gx, &gy);
+    dim3 grid(gx, gy);
+    if (nt2)
+        hipLaunchKernelGGL((conv3_s1_pc_kernel<TD, TH, TW, MT, 2, SWZ>), grid, dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv3_s1_pc_kernel<TD, TH, TW, MT, 1, SWZ>), grid, dim3(512), 0, st, a);
+    return ru3d_check_launch("conv3_s1_pc");
+}
+
 template <int TD, int TH, int TW, int MT>
 static int launch_s1(const MfmaConvArgs& a0, bool nt2, hipStream_t st) {
     MfmaConvArgs a = a0;
@@ -242,25 +550,111 @@ static int launch_s1(const MfmaConvArgs& a0, bool nt2, hipStream_t st) {
 
 // Tile choice: W decides the tile's aspect; if the 256-voxel x 64-cout decomposition yields fewer than ~2
 // workgroups per CU (deep levels: 16^3, 8^3), fall back to 128-voxel tiles and then to 32-cout slices.
-static int launch_s1_auto(const MfmaConvArgs& a, hipStream_t st) {
+// >= 2 (tile, cout-slice) units per CU run on the persistent producer/consumer kernel.
+struct S1Plan {
+    int wclass;
+    bool nt2, small, pc;
+    int64_t nblk_pc;   // spatial tiles of the producer/consumer decomposition
+};
+
+static S1Plan s1_plan(int N, int D, int H, int W, int Cout) {
     auto cdiv = [](int x, int y) { return (x + y - 1) / y; };
-    const bool can_nt2 = (a.Cout % 64) == 0;
-    const int wclass = a.W >= 24 ? 32 : (a.W >= 12 ? 16 : 8);
+    S1Plan p;
+    const bool can_nt2 = (Cout % 64) == 0;
+    p.wclass = W >= 24 ? 32 : (W >= 12 ? 16 : 8);
     int64_t big;   // workgroups with MT = 2, widest cout slice
-    if (wclass == 32) big = (int64_t)a.N * cdiv(a.D, 2) * cdiv(a.H, 4) * cdiv(a.W, 32);
-    else if (wclass == 16) big = (int64_t)a.N * cdiv(a.D, 2) * cdiv(a.H, 8) * cdiv(a.W, 16);
-    else big = (int64_t)a.N * cdiv(a.D, 4) * cdiv(a.H, 8) * cdiv(a.W, 8);
-    big *= a.Cout / (can_nt2 ? 64 : 32);
-    const bool small = big < 512;
-    const bool nt2 = can_nt2 && (!small || big * 2 >= 1024);
-    if (!small) {
-        if (wclass == 32) return launch_s1<2, 4, 32, 2>(a, nt2, st);
-        if (wclass == 16) return launch_s1<2, 8, 16, 2>(a, nt2, st);
-        return launch_s1<4, 8, 8, 2>(a, nt2, st);
+    if (p.wclass == 32) big = (int64_t)N * cdiv(D, 2) * cdiv(H, 4) * cdiv(W, 32);
+    else if (p.wclass == 16) big = (int64_t)N * cdiv(D, 2) * cdiv(H, 8) * cdiv(W, 16);
+    else big = (int64_t)N * cdiv(D, 4) * cdiv(H, 8) * cdiv(W, 8);
+    p.nblk_pc = big;
+    big *= Cout / (can_nt2 ? 64 : 32);
+    p.small = big < 512;
+    p.nt2 = can_nt2 && (!p.small || big * 2 >= 1024);
+    static const int pc_mode = getenv("RU3D_CONV_PC") ? atoi(getenv("RU3D_CONV_PC")) : 1;   // 0 = off
+    p.pc = !p.small && pc_mode >= 1 && p.wclass >= 16;
+    return p;
+}
+
+static int launch_s1_auto(const MfmaConvArgs& a, hipStream_t st) {
+    const S1Plan p = s1_plan(a.N, a.D, a.H, a.W, a.Cout);
+    if (a.stat_slab && !p.pc) return ru3d_fail(-1, "conv_mfma: fused statistics need the producer/consumer kernel");
+    if (!p.small) {
+        if (p.pc && p.wclass == 32) return launch_s1_pc<2, 4, 32, 2, false>(a, p.nt2, st);
+        if (p.pc && p.wclass == 16) return launch_s1_pc<2, 8, 16, 2, false>(a, p.nt2, st);
+        if (p.wclass == 32) return launch_s1<2, 4, 32, 2>(a, p.nt2, st);
+        if (p.wclass == 16) return launch_s1<2, 8, 16, 2>(a, p.nt2, st);
+        return launch_s1<4, 8, 8, 2>(a, p.nt2, st);
     }
-    if (wclass == 32) return launch_s1<1, 4, 32, 1>(a, nt2, st);
-    if (wclass == 16) return launch_s1<1, 8, 16, 1>(a, nt2, st);
-    return launch_s1<2, 8, 8, 1>(a, nt2, st);
+    if (p.wclass == 32) return launch_s1<1, 4, 32, 1>(a, p.nt2, st);
+    if (p.wclass == 16) return launch_s1<1, 8, 16, 1>(a, p.nt2, st);
+    return launch_s1<2, 8, 8, 1>(a, p.nt2, st);
+}
+
+// Fused InstanceNorm statistics (producer/consumer kernel only): slab[workgroup][wave][n][cout_local][2] floats.
+bool mfma_conv_can_fuse_stats(const ConvGeom& g) {
+    if (!(g.k == 3 && g.stride == 1 && !g.transposed && (g.Cin % 32) == 0 && (g.Cout % 32) == 0)) return false;
+    return s1_plan(g.N, g.Do, g.Ho, g.Wo, g.Cout).pc;
+}
+
+static void stats_slab_geom(const ConvGeom& g, int* gx, int* gy, int* cb) {
+    const S1Plan p = s1_plan(g.N, g.Do, g.Ho, g.Wo, g.Cout);
+    pc_grid(g.Cout, p.nt2, p.nblk_pc, gx, gy);
+    *cb = p.nt2 ? 64 : 32;
+}
+
+size_t mfma_conv_stats_slab_bytes(const ConvGeom& g) {
+    int gx, gy, cb;
+    stats_slab_geom(g, &gx, &gy, &cb);
+    return (size_t)gx * gy * 4 * g.N * cb * 2 * sizeof(float);
+}
+
+// mean / scale from the slabs: one thread block per (n, 16 channels); 16 lanes per channel sum the
+// (workgroup, wave) partials in a fixed order, in double.
+__global__ __launch_bounds__(256) void stats_slab_finalize_kernel(const float* __restrict__ slab, int gx, int cb, int N,
+                                                                  int C, double invV, const float* __restrict__ drop,
+                                                                  float eps, float* __restrict__ mean,
+                                                                  float* __restrict__ scale) {
+    __shared__ double sh[2][16][16];
+    const int cx = threadIdx.x & 15, ky = threadIdx.x >> 4;
+    const int n = blockIdx.y, c = blockIdx.x * 16 + cx;
+    double a1 = 0.0, a2 = 0.0;
+    if (c < C) {
+        const int y = c / cb, cl = c % cb;
+        const int parts = gx * 4;   // (workgroup x, wave) pairs that hold channel c
+        for (int p = ky; p < parts; p += 16) {
+            const float* e = slab + ((((int64_t)(y * gx + (p >> 2)) * 4 + (p & 3)) * N + n) * cb + cl) * 2;
+            a1 += (double)e[0];
+            a2 += (double)e[1];
+        }
+    }
+    sh[0][ky][cx] = a1;
+    sh[1][ky][cx] = a2;
+    __syncthreads();
+    if (ky == 0 && c < C) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int k = 0; k < 16; k++) {
+            t1 += sh[0][k][cx];
+            t2 += sh[1][k][cx];
+        }
+        const double m = t1 * invV;
+        double var = t2 * invV - m * m;
+        if (var < 0.0) var = 0.0;
+        const int i = n * C + c;
+        const double sdrop = drop ? (double)drop[i] : 1.0;
+        mean[i] = (float)m;
+        scale[i] = (float)(sdrop / sqrt(sdrop * sdrop * var + (double)eps));
+    }
+}
+
+int mfma_conv_stats_finalize(const ConvGeom& g, const float* slab, const float* drop, float eps, float* mean,
+                             float* scale, hipStream_t st) {
+    int gx, gy, cb;
+    stats_slab_geom(g, &gx, &gy, &cb);
+    dim3 grid((g.Cout + 15) / 16, g.N);
+    const double invV = 1.0 / ((double)g.Do * g.Ho * g.Wo);
+    hipLaunchKernelGGL(stats_slab_finalize_kernel, grid, dim3(256), 0, st, slab, gx, cb, g.N, g.Cout, invV, drop, eps,
+                       mean, scale);
+    return ru3d_check_launch("stats_slab_finalize");
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -459,13 +853,15 @@ static bool aligned_to(const void* p, size_t a) { return (((uintptr_t)p) % a) ==
 bool mfma_conv_geometry_ok(const ConvGeom& g) { return !g.transposed || g.stride == 2; }
 
 int conv_mfma_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
-                     hipStream_t st) {
+                     hipStream_t st, float* stat_slab) {
     if (!mfma_conv_geometry_ok(g)) return ru3d_fail(-1, "conv_mfma: geometry not supported");
     if ((g.ldx % 8) || (g.ldy % 4) || (res && (g.ldr % 4)) || !aligned_to(x, 16) || !aligned_to(y, 8) ||
         (res && !aligned_to(res, 8)) || (bias && !aligned_to(bias, 16)) || !aligned_to(w, 16))
         return ru3d_fail(-1, "conv_mfma: operands must be 16-byte (x, w, bias) / 8-byte (y, res) aligned");
-    if (!(g.k == 3 && g.stride == 1 && !g.transposed && (g.Cin % 32) == 0))
+    if (!(g.k == 3 && g.stride == 1 && !g.transposed && (g.Cin % 32) == 0)) {
+        if (stat_slab) return ru3d_fail(-1, "conv_mfma: fused statistics not available for this form");
         return launch_direct(x, w, bias, res, y, g, st);
+    }
     MfmaConvArgs a;
     a.x = (const bf16*)x;
     a.w = (const bf16x8*)w;
@@ -475,6 +871,7 @@ int conv_mfma_launch(const void* x, const void* w, const float* bias, const void
     a.N = g.N; a.D = g.Do; a.H = g.Ho; a.W = g.Wo;
     a.Cin = g.Cin; a.Cout = g.Cout; a.ldx = g.ldx; a.ldy = g.ldy; a.ldr = g.ldr;
     a.flip = g.flip;
+    a.stat_slab = stat_slab;
     return launch_s1_auto(a, st);
 }
 

@@ -70,10 +70,10 @@ class Adam(torch.optim.Optimizer):
             step_no = None
             any_grad = False
             for i, p in enumerate(params):
-                st = self.state[p]
                 if p.grad is None:
                     arr[i] = _AdamTensor(p.data_ptr(), None, None, None, p.numel())
                     continue
+                st = self.state[p]
                 g = p.grad
                 if g.dtype != torch.float32 or not g.is_contiguous():
                     g = g.float().contiguous()

@@ -89,6 +89,14 @@ int ru3d_pack_weights(const ru3d_pack_item* items, int count, int dtype, void* s
  * while x is bf16 (the logits head). */
 int ru3d_conv3d_fwd(const ru3d_tensor* x, const void* w_packed, const float* bias, const ru3d_tensor* res,
                     const ru3d_tensor* y, int k, int stride, int dtype, int y_dtype, void* stream);
+/* The same forward conv FOLLOWED by the InstanceNorm statistics of its output (ResBlock: conv -> dropout ->
+ * norm, network.py:411-414): y = conv(x) + bias, then mean / scale exactly as ru3d_instnorm_stats(y, ...)
+ * would produce.  On the producer/consumer MFMA kernel the sums are accumulated in the conv epilogue (no
+ * second pass over y); other shapes run the two kernels back to back.  Workspace from the _bytes query. */
+size_t ru3d_conv3d_fwd_in_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* y, int k, int stride, int dtype);
+int ru3d_conv3d_fwd_in(const ru3d_tensor* x, const void* w_packed, const float* bias, const ru3d_tensor* y, int k,
+                       int stride, int dtype, const float* drop_scale, float* mean, float* scale, void* ws,
+                       size_t ws_bytes, float eps, void* stream);
 /* input gradient of the same conv: dx = conv_dgrad(dy) (+ res).  w_packed made with ROLE_CONV_DGRAD. */
 int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* res,
                       const ru3d_tensor* dx, int k, int stride, int dtype, void* stream);

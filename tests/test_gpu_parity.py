@@ -511,6 +511,29 @@ def test_mfma_convtranspose_bf16(cin, cout, dims):
     _close(gw, wr.grad, 2e-3, 1e-3, "convT wgrad")
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 32, 40, 36, 64), (1, 64, 64, 33, 40, 48), (3, 32, 64, 24, 24, 24),
+                                   (1, 32, 32, 6, 6, 8)])
+def test_conv_fwd_in_fused_statistics(shape):
+    """ru3d_conv3d_fwd_in: conv + InstanceNorm statistics.  On the persistent producer/consumer MFMA kernel the
+    sums come from the conv epilogue; they must agree with a separate statistics pass over the stored output
+    (same bf16 values, different summation order), with and without a Dropout3d factor; small shapes take the
+    two-kernel route."""
+    n, cin, cout, d, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = ops.as_input((torch.randn(n, cin, d, h, w, generator=g) + 0.3).to(DEV), torch.bfloat16)
+    wt = torch.randn(cout, cin, 3, 3, 3, generator=g) * (1.0 / (27 * cin) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    pw = ops.pack_weight(wt.to(DEV), N.ROLE_CONV_FWD, torch.bfloat16, 1)
+    drop = (torch.rand(n * cout, generator=g) > 0.5).float().mul(2.0).to(DEV)
+    for ds in (None, drop):
+        y, mean, scale = ops.conv_fwd_in(x, pw, b.to(DEV), cout, 3, 1, ds)
+        y_ref = ops.conv_fwd(x, pw, b.to(DEV), cout, 3, 1)
+        assert torch.equal(y, y_ref)
+        mean_s, scale_s = ops.in_stats(y, ds)
+        assert (mean - mean_s).abs().max().item() <= 1e-5 * max(1.0, mean_s.abs().max().item())
+        assert (scale - scale_s).abs().max().item() <= 2e-5 * max(1.0, scale_s.abs().max().item())
+
+
 def test_norm_kernels_vs_oracle_bf16_and_fp32():
     g = torch.Generator().manual_seed(12)
     for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
