@@ -608,34 +608,26 @@ size_t mfma_conv_stats_slab_bytes(const ConvGeom& g) {
     return (size_t)gx * gy * 4 * g.N * cb * 2 * sizeof(float);
 }
 
-// mean / scale from the slabs: one thread block per (n, 16 channels); 16 lanes per channel sum the
+// mean / scale from the slabs: one thread block per (n, 4 channels); 64 lanes per channel sum the
 // (workgroup, wave) partials in a fixed order, in double.
 __global__ __launch_bounds__(256) void stats_slab_finalize_kernel(const float* __restrict__ slab, int gx, int cb, int N,
                                                                   int C, double invV, const float* __restrict__ drop,
                                                                   float eps, float* __restrict__ mean,
                                                                   float* __restrict__ scale) {
-    __shared__ double sh[2][16][16];
-    const int cx = threadIdx.x & 15, ky = threadIdx.x >> 4;
-    const int n = blockIdx.y, c = blockIdx.x * 16 + cx;
+    const int lane = threadIdx.x & 63, cx = threadIdx.x >> 6;
+    const int n = blockIdx.y, c = blockIdx.x * 4 + cx;
     double a1 = 0.0, a2 = 0.0;
     if (c < C) {
         const int y = c / cb, cl = c % cb;
         const int parts = gx * 4;   // (workgroup x, wave) pairs that hold channel c
-        for (int p = ky; p < parts; p += 16) {
+        for (int p = lane; p < parts; p += 64) {
             const float* e = slab + ((((int64_t)(y * gx + (p >> 2)) * 4 + (p & 3)) * N + n) * cb + cl) * 2;
             a1 += (double)e[0];
             a2 += (double)e[1];
         }
     }
-    sh[0][ky][cx] = a1;
-    sh[1][ky][cx] = a2;
-    __syncthreads();
-    if (ky == 0 && c < C) {
-        double t1 = 0.0, t2 = 0.0;
-        for (int k = 0; k < 16; k++) {
-            t1 += sh[0][k][cx];
-            t2 += sh[1][k][cx];
-        }
+    const double t1 = wave_sum_d(a1), t2 = wave_sum_d(a2);   // xor-butterfly: fixed order
+    if (lane == 0 && c < C) {
         const double m = t1 * invV;
         double var = t2 * invV - m * m;
         if (var < 0.0) var = 0.0;
@@ -650,7 +642,7 @@ int mfma_conv_stats_finalize(const ConvGeom& g, const float* slab, const float* 
                              float* scale, hipStream_t st) {
     int gx, gy, cb;
     stats_slab_geom(g, &gx, &gy, &cb);
-    dim3 grid((g.Cout + 15) / 16, g.N);
+    dim3 grid((g.Cout + 3) / 4, g.N);
     const double invV = 1.0 / ((double)g.Do * g.Ho * g.Wo);
     hipLaunchKernelGGL(stats_slab_finalize_kernel, grid, dim3(256), 0, st, slab, gx, cb, g.N, g.Cout, invV, drop, eps,
                        mean, scale);
@@ -1084,20 +1076,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_staged_mfma_kernel(StagedWgradAr
                 if (pv) v = *reinterpret_cast<const bf16x8*>(a.dy + pos * a.lddy + cot * 32 + part * 8);
                 *reinterpret_cast<bf16x8*>(&ds[pl * 32 + part * 8]) = v;
             }
-            // taps owned by this thread: TAPS == 27 -> (tid >> 7) + 2 i ; TAPS == 1 -> tap 0
+            // taps owned by this thread: TAPS == 27 -> (tid >> 7) + 2 i ; TAPS == 1 -> tap 0.
+            // All gathers are issued first (registers), the LDS writes follow: one exposed latency per tile.
             constexpr int TAP_ITERS = (TAPS == 27) ? 14 : 1;
+            bf16x8 sx[TAP_ITERS];
 #pragma unroll
             for (int i = 0; i < TAP_ITERS; i++) {
                 const int tap = (TAPS == 27) ? ((tid >> 7) + 2 * i) : 0;
-                if (tap >= TAPS) break;
                 const int kd = tap / (K * K), kh = (tap / K) % K, kw = tap % K;
                 const int id = od * a.stride + kd - a.pad, ih = oh * a.stride + kh - a.pad,
                           iw = ow * a.stride + kw - a.pad;
                 bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (pv && id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
+                if (tap < TAPS && pv && id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
                     v = *reinterpret_cast<const bf16x8*>(a.x + ((((int64_t)n * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.ldx +
                                                          cit * 32 + part * 8);
-                *reinterpret_cast<bf16x8*>(&xs[(tap * PT + pl) * 32 + part * 8]) = v;
+                sx[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < TAP_ITERS; i++) {
+                const int tap = (TAPS == 27) ? ((tid >> 7) + 2 * i) : 0;
+                if (tap < TAPS) *reinterpret_cast<bf16x8*>(&xs[(tap * PT + pl) * 32 + part * 8]) = sx[i];
             }
         }
         __syncthreads();

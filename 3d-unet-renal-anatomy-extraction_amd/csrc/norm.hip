@@ -55,6 +55,7 @@ static int pick_vec(int c, std::initializer_list<const ru3d_tensor*> ts) {
 // MODE 0: (sum y, sum y^2)                                 InstanceNorm statistics
 // MODE 1: (sum gpre, sum gpre*xhat)                        InstanceNorm backward
 // MODE 2: (sum t, 0)                                       bias gradient
+// MODE 3: as MODE 1 with xhat recovered from the activation (no residual in the forward: out = lrelu(xhat))
 // Partials: part[((n*chunks + chunk)*C + c)*2 + {0,1}] as double.
 template <typename T, int VEC, int MODE>
 __global__ __launch_bounds__(256) void reduce2_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b,
@@ -100,6 +101,17 @@ __global__ __launch_bounds__(256) void reduce2_kernel(const T* __restrict__ a, i
                 for (int i = 0; i < VEC; i++) {
                     const float gp = ov[i] > 0.f ? av[i] : av[i] * slope;
                     const float xh = (yv[i] - mu[i]) * sc[i];
+                    s1[i] += gp;
+                    s2[i] = fmaf(gp, xh, s2[i]);
+                }
+            } else if (MODE == 3) {
+                float ov[VEC];
+                load_vec<T, VEC>(b + row * ldb + cg * VEC, ov);
+                const float inv_slope = 1.f / slope;
+#pragma unroll
+                for (int i = 0; i < VEC; i++) {
+                    const float gp = ov[i] > 0.f ? av[i] : av[i] * slope;
+                    const float xh = ov[i] > 0.f ? ov[i] : ov[i] * inv_slope;
                     s1[i] += gp;
                     s2[i] = fmaf(gp, xh, s2[i]);
                 }
@@ -279,7 +291,7 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(const T* __restrict__
         float gv[VEC], ov[VEC], yv[VEC], dv[VEC], pv[VEC];
         load_vec<T, VEC>(gout + row * ldg + cg * VEC, gv);
         load_vec<T, VEC>(out + row * ldo + cg * VEC, ov);
-        load_vec<T, VEC>(y + row * ldy + cg * VEC, yv);
+        if (HAS_GPRE) load_vec<T, VEC>(y + row * ldy + cg * VEC, yv);   // no residual: xhat comes from `out`
         bool far = false;
         if (zero_far) {
             const int w = v % W, h = (v / W) % H, d = v / (W * H);
@@ -288,7 +300,7 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(const T* __restrict__
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
             const float gp = ov[i] > 0.f ? gv[i] : gv[i] * slope;
-            const float xh = (yv[i] - mu[i]) * sc[i];
+            const float xh = HAS_GPRE ? (yv[i] - mu[i]) * sc[i] : (ov[i] > 0.f ? ov[i] : ov[i] / slope);
             pv[i] = gp;
             dv[i] = far ? 0.f : sc[i] * (gp - m1[i] - xh * m2[i]);
         }
@@ -420,8 +432,13 @@ static int in_bwd_impl(const ru3d_tensor* gout, const ru3d_tensor* out, const ru
     const int NC = y->n * y->c;
     float* m12 = (float*)((char*)ws + (size_t)y->n * cl.chunks * y->c * 2 * sizeof(double));
 #define CALL(TT, VV)                                                                                                  \
-    hipLaunchKernelGGL((reduce2_kernel<TT, VV, 1>), grid, dim3(256), 0, st, (const TT*)gout->ptr, gout->ld,           \
-                       (const TT*)out->ptr, out->ld, (const TT*)y->ptr, y->ld, mean, scale, slope, part, cl, y->c)
+    if (gpre)                                                                                                         \
+        hipLaunchKernelGGL((reduce2_kernel<TT, VV, 1>), grid, dim3(256), 0, st, (const TT*)gout->ptr, gout->ld,       \
+                           (const TT*)out->ptr, out->ld, (const TT*)y->ptr, y->ld, mean, scale, slope, part, cl,      \
+                           y->c);                                                                                     \
+    else                                                                                                              \
+        hipLaunchKernelGGL((reduce2_kernel<TT, VV, 3>), grid, dim3(256), 0, st, (const TT*)gout->ptr, gout->ld,       \
+                           (const TT*)out->ptr, out->ld, (const TT*)0, 0, mean, scale, slope, part, cl, y->c)
     DISPATCH_VEC(T, vec, CALL)
 #undef CALL
     int rc = ru3d_check_launch("in_lrelu_bwd_reduce");

@@ -128,9 +128,11 @@ int ru3d_instnorm_stats(const ru3d_tensor* y, const float* drop_scale, float* me
 /* out = LeakyReLU((y - mean) * scale (+ res), slope)  (network.py:414,416; 315-316). */
 int ru3d_in_lrelu_fwd(const ru3d_tensor* y, const float* mean, const float* scale, const ru3d_tensor* res,
                       const ru3d_tensor* out, float slope, int dtype, void* stream);
-/* backward of the above: given gout = dL/dout, writes dy = dL/dy and (optionally, when the forward
- * had a residual) gpre = gout * LeakyReLU'(out) = dL/dres.  zero_far=1 additionally zeroes the last
- * plane of each spatial axis of dy (the constant-pad planes of ConvTrans3D). */
+/* backward of the above: given gout = dL/dout, writes dy = dL/dy and, when the forward had a residual,
+ * gpre = gout * LeakyReLU'(out) = dL/dres.  CONTRACT: gpre != NULL <=> the forward was called with a residual.
+ * Without a residual out = LeakyReLU(x_hat) is invertible, so x_hat is recovered from `out` and `y` is not
+ * read at all (one tensor pass less in each of the two kernels).  zero_far=1 additionally zeroes the last plane
+ * of each spatial axis of dy (the constant-pad planes of ConvTrans3D). */
 int ru3d_in_lrelu_bwd(const ru3d_tensor* gout, const ru3d_tensor* out, const ru3d_tensor* y, const float* mean,
                       const float* scale, const ru3d_tensor* dy, const ru3d_tensor* gpre, void* ws,
                       size_t ws_bytes, float slope, int zero_far, int dtype, void* stream);
