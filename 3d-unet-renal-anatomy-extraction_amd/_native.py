@@ -70,6 +70,8 @@ SIGNATURES = {
                            _sz, _vp]),
     "ru3d_loss_bwd": (_i, [_vp, _i64, _i64, _i64, _vp, _i, _i, _i64, _i, _f, _vp, _vp, _vp, _i, _vp]),
     "ru3d_tversky": (_i, [_vp, _vp, _i64, _f, _f, _f, _vp, _vp, _sz, _vp]),
+    "ru3d_predict_accumulate": (_i, [_P, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ru3d_predict_merge": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ru3d_adam_multi": (_i, [_vp, _vp, _i, _i, _f, _f, _f, _f, _f, _f, _f, _vp]),
     "ru3d_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp]),
 }

@@ -35,6 +35,7 @@ except Exception:
     SummaryWriter = None
 
 from loss import dice  # noqa: F401  (re-exported like the reference: trainer.dice)
+from inference import predict_per_patch  # noqa: F401  (reference trainer.py:17)
 
 
 class _NullBar:

@@ -174,6 +174,21 @@ int ru3d_loss_bwd(const float* logits, int64_t stride_n, int64_t stride_c, int64
 int ru3d_tversky(const float* p, const float* g, int64_t count, float alpha, float beta, float smooth,
                  float* out, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------ sliding-window inference */
+/* predict_per_patch (trainer.py:17-98).  `acc` is a zero-initialised [X, Y, Z, C] fp32 volume, `cnt` a
+ * zero-initialised [X, Y, Z] fp32 volume (the reference's `result` / `result_n`, trainer.py:42-43).
+ * accumulate: acc[window] += softmax_c(logits[sample]) (sigmoid when C == 1), cnt[window] += 1, the window
+ * being [ox, ox+d) x [oy, oy+h) x [oz, oz+w) (trainer.py:72-80).  Launches for overlapping windows must be
+ * issued on one stream; the sum order is then the launch order, as in the reference's patch loop. */
+int ru3d_predict_accumulate(const ru3d_tensor* logits, int dtype, int sample, float* acc, float* cnt, int X, int Y,
+                            int Z, int ox, int oy, int oz, void* stream);
+/* merge (trainer.py:85-98) over the crop [cx, cx+sx) x [cy, cy+sy) x [cz, cz+sz) of the padded volume:
+ * one_hot != 0: out = float [sx, sy, sz, C] = acc / cnt (NaN where no window reached, as in the reference);
+ * one_hot == 0: out = uint8 [sx, sy, sz]: C == 1 -> round(acc / cnt); C > 1 -> argmax_c softmax_c(acc / cnt)
+ * (the reference's second softmax); uncovered voxels -> 0. */
+int ru3d_predict_merge(const float* acc, const float* cnt, int X, int Y, int Z, int num_classes, int cx, int cy,
+                       int cz, int sx, int sy, int sz, int one_hot, void* out, void* stream);
+
 /* ------------------------------------------------------------------ optimizer --------------- */
 /* torch.optim.Adam step (nb_train_iia.py:18 defaults), fused over one flat fp32 parameter run.
  * grad may be bf16/f32 (grad_dtype); bias corrections are passed in by the host. */

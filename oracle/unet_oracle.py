@@ -370,3 +370,62 @@ def phantom_labels(n, dims, num_classes):
             s = (zz - cz - 0.15 * d) ** 2 + (yy - cy) ** 2 + (xx - cx) ** 2
             lab[i][s <= (0.06 * min(dims)) ** 2] = 3
     return torch.from_numpy(lab)
+
+
+# --------------------------------------------------------------------------- sliding-window inference
+def center_crop_pad(a, size, cval=0):
+    """transform.py:392-432 (crop_pad, crop_mode 'center', constant padding) on the leading len(size) axes."""
+    a = np.asarray(a)
+    box = []
+    for i in range(a.ndim):
+        if i < len(size):
+            lo = (a.shape[i] - size[i]) // 2
+            box.append((lo, lo + size[i]))
+        else:
+            box.append((0, a.shape[i]))
+    cut = a[tuple(slice(max(0, lo), min(hi, a.shape[i])) for i, (lo, hi) in enumerate(box))]
+    width = [(abs(min(0, lo)), abs(min(0, a.shape[i] - hi))) for i, (lo, hi) in enumerate(box)]
+    if any(v > 0 for pair in width for v in pair):
+        cut = np.pad(cut, width, "constant", constant_values=cval)
+    return cut.astype(a.dtype)
+
+
+def predict_per_patch(image, w, num_pool, num_classes=3, patch_size=(96, 96, 96), step_per_patch=4, one_hot=False):
+    """trainer.py:17-98 with the model call replaced by `unet_forward(., w, num_pool)`.
+
+    image: numpy [X, Y, Z, C].  `np.int` (removed in numpy 1.24) was the builtin int, so the centres are
+    np.arange(..., dtype=int) exactly as the reference computes them (trainer.py:38-40)."""
+    orig = image.shape[:3]
+    image = center_crop_pad(image, [max(image.shape[d], patch_size[d]) for d in range(3)])     # transform.pad
+    full = image.shape[:3]
+    start = np.array([p // 2 for p in patch_size])
+    end = np.array([full[i] - patch_size[i] // 2 for i in range(3)])
+    num_steps = np.ceil([(end[i] - start[i]) / (patch_size[i] / step_per_patch) for i in range(3)])
+    step = np.array([(end[i] - start[i]) / (num_steps[i] + 1e-8) for i in range(3)])
+    step[step == 0] = 9999999
+    axes = [np.arange(start[i], end[i] + 1e-8, step[i], dtype=int) for i in range(3)]
+    result = torch.zeros([num_classes] + list(full))
+    result_n = torch.zeros_like(result)
+    x = torch.from_numpy(np.moveaxis(image, -1, 0)[None].astype(np.float32))                    # to_tensor
+    with torch.no_grad():
+        for cx in axes[0]:
+            for cy in axes[1]:
+                for cz in axes[2]:
+                    win = (slice(cx - patch_size[0] // 2, cx + patch_size[0] // 2),
+                           slice(cy - patch_size[1] // 2, cy + patch_size[1] // 2),
+                           slice(cz - patch_size[2] // 2, cz + patch_size[2] // 2))
+                    out = unet_forward(x[(slice(None), slice(None)) + win], w, num_pool)
+                    out = torch.sigmoid(out) if num_classes == 1 else torch.softmax(out, dim=1)
+                    result[(slice(None),) + win] += out[0]
+                    result_n[(slice(None),) + win] += 1
+    result = result / result_n
+    if one_hot:
+        result = np.moveaxis(result.numpy(), 0, -1).astype(np.float32)                          # to_numpy
+    else:
+        if num_classes == 1:
+            result = torch.squeeze(result, dim=0)
+        else:
+            result = torch.argmax(torch.softmax(result, dim=0), dim=0)
+        with np.errstate(invalid="ignore"):
+            result = np.round(result.numpy()).astype(np.uint8)
+    return center_crop_pad(result, orig), [a.tolist() for a in axes]

@@ -17,6 +17,14 @@ Groups:
   g3_loss.npz      each loss/metric with nb_train_iia.py hyper-parameters: value + d/dlogits
   g4_quirks.json   quirk pins (weight_c ignored, absent-class weighting, C==1 raises)
   g5_checkpoint.json  key names/shapes of a Trainer.save_checkpoint-shaped dict
+  g6_predict.npz   trainer.predict_per_patch (sliding-window inference): volumes, weights, uint8 masks
+                   and one-hot probability maps, incl. the uncovered-border (0/0 -> class 0) quirk
+
+G6 imports the reference's trainer.py.  Its module header imports third-party packages that are not
+installed here (apex, torchsummary, tensorboard, nibabel, transforms3d) and that predict_per_patch
+never touches; those names are registered as empty placeholder modules for the import only.  The
+function also uses `np.int`, an alias of the builtin `int` that numpy removed in 1.24; the alias is
+restored for the duration of the call.  transform.py (numpy + scipy) is imported for real.
 """
 import importlib.util
 import json
@@ -310,6 +318,71 @@ def make_g5():
     print("g5: %d state_dict keys, %d params" % (len(info["model_state_dict"]), info["num_parameters"]))
 
 
+# --------------------------------------------------------------------------- G6
+def _load_ref_trainer():
+    import types
+    placeholders = {
+        "apex": {"amp": None}, "torchsummary": {"summary": None}, "nibabel": {},
+        "torch.utils.tensorboard": {"SummaryWriter": None},
+        "data": {k: None for k in ("CaseDataset", "load_case", "save_pred", "orient_crop_case",
+                                   "regions_crop_case", "resample_normalize_case")},
+    }
+    saved = {}
+    for name, attrs in placeholders.items():
+        saved[name] = sys.modules.get(name)
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+    sys.modules["loss"] = ref_loss
+    sys.modules["transform"] = _load("transform")
+    try:
+        return _load("trainer")
+    finally:
+        for name, old in saved.items():
+            if old is None:
+                sys.modules.pop(name, None)
+            else:
+                sys.modules[name] = old
+        sys.modules.pop("loss", None)
+        sys.modules.pop("transform", None)
+
+
+def make_g6():
+    ref_trainer = _load_ref_trainer()
+    had = hasattr(np, "int")
+    if not had:
+        np.int = int
+    out = {}
+    cases = [
+        # tag, volume shape, patch, step_per_patch, (num_pool, F, out_channels)
+        ("a", (21, 19, 13), (16, 16, 8), 4, (2, 4, 3)),      # ragged steps, uncovered far border
+        ("b", (11, 24, 10), (16, 16, 8), 2, (2, 4, 3)),      # axis 0 shorter than the patch by an odd amount:
+                                                             # padded 3 in front, cropped back at offset 2
+        ("c", (16, 16, 8), (16, 16, 8), 4, (2, 4, 3)),       # exactly one patch (step_size 0 -> 9999999)
+        ("d", (20, 17, 9), (16, 16, 8), 4, (1, 4, 1)),       # single class: sigmoid, no second softmax
+    ]
+    try:
+        for tag, shape, patch, spp, (pool, feat, ncls) in cases:
+            torch.manual_seed(60 + ord(tag))
+            model = ref_network.ResUnet3D(num_pool=pool, num_features=feat, in_channels=1, out_channels=ncls)
+            vol = synth_image(shape + (1,), 600 + ord(tag)).numpy().copy()
+            out[tag + "/image"] = vol
+            out[tag + "/patch"] = np.array(patch)
+            out[tag + "/meta"] = np.array([spp, pool, feat, ncls])
+            out.update(sd_np(model.state_dict(), tag + "/w/"))
+            mask = ref_trainer.predict_per_patch(vol.copy(), model, ncls, patch, spp, False, False)
+            prob = ref_trainer.predict_per_patch(vol.copy(), model, ncls, patch, spp, False, True)
+            out[tag + "/mask"] = np.asarray(mask).copy()
+            out[tag + "/prob"] = np.asarray(prob).copy()
+            print("g6/%s: mask %s %s classes %s, prob %s nan=%d" % (
+                tag, mask.shape, mask.dtype, np.unique(mask).tolist(), prob.shape, int(np.isnan(prob).sum())))
+    finally:
+        if not had:
+            del np.int
+    np.savez_compressed(os.path.join(OUT, "g6_predict.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     make_g1()
@@ -318,3 +391,4 @@ if __name__ == "__main__":
     make_g3_loss()
     make_g4()
     make_g5()
+    make_g6()

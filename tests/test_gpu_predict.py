@@ -1,0 +1,142 @@
+"""Sliding-window inference (`trainer.predict_per_patch`) on the HIP path against the reference's own outputs
+(tests/golden/g6_predict.npz, made by the reference's function) and against the CPU oracle.  `-m gpu` only.
+
+Tolerances: averaged probabilities within 5e-6 abs in fp32 mode (logits agree to ~1e-5, a softmax output moves
+by at most a quarter of the logit error, and up to 24 windows are averaged); the never-visited border is NaN in
+the same voxels; masks are identical except where the reference's own top-2 probability margin is below 1e-5."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip("no HIP device", allow_module_level=True)
+
+import _native as N  # noqa: E402
+import inference as I  # noqa: E402
+import network  # noqa: E402
+import trainer as T  # noqa: E402
+from oracle import unet_oracle as O  # noqa: E402
+
+DEV = torch.device("cuda:0")
+
+
+def _case(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, "g6_predict.npz"))
+    patch = tuple(int(v) for v in g[tag + "/patch"])
+    spp, pool, feat, ncls = (int(v) for v in g[tag + "/meta"])
+    model = network.ResUnet3D(num_pool=pool, num_features=feat, in_channels=1, out_channels=ncls)
+    model.load_state_dict({k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "/w/")},
+                          strict=True)
+    return g, g[tag + "/image"], patch, spp, ncls, model.to(DEV)
+
+
+def _margin(prob):
+    if prob.shape[-1] == 1:
+        return np.abs(prob[..., 0] - 0.5)
+    s = np.sort(np.nan_to_num(prob, nan=0.0), axis=-1)
+    return s[..., -1] - s[..., -2]
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+@pytest.mark.parametrize("patch_batch", [1, 3])
+def test_predict_per_patch_vs_reference_fixture(golden_dir, tag, patch_batch):
+    g, image, patch, spp, ncls, model = _case(golden_dir, tag)
+    gm, gp = g[tag + "/mask"], g[tag + "/prob"]
+    prob = T.predict_per_patch(image, model, ncls, patch, spp, False, True, patch_batch=patch_batch)
+    mask = T.predict_per_patch(image, model, ncls, patch, spp, False, False, patch_batch=patch_batch)
+    assert prob.dtype == np.float32 and prob.shape == gp.shape
+    assert np.array_equal(np.isnan(prob), np.isnan(gp))
+    assert np.nanmax(np.abs(prob - gp)) < 5e-6
+    assert mask.dtype == np.uint8 and mask.shape == gm.shape
+    diff = mask != gm
+    assert not (diff & (_margin(gp) > 1e-5)).any()
+    assert diff.mean() < 1e-3
+    assert (mask[np.isnan(gp).any(axis=-1)] == 0).all()
+
+
+def test_patch_batch_does_not_change_the_result(golden_dir):
+    g, image, patch, spp, ncls, model = _case(golden_dir, "a")
+    a = T.predict_per_patch(image, model, ncls, patch, spp, False, True, patch_batch=1)
+    b = T.predict_per_patch(image, model, ncls, patch, spp, False, True, patch_batch=5)
+    assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_predict_kernels_against_numpy_on_random_windows():
+    """ru3d_predict_accumulate / ru3d_predict_merge alone: random logits, overlapping windows, 1..4 classes,
+    fp32 and bf16 logits, a crop offset; compared with the same arithmetic in numpy/torch on the CPU."""
+    import ctypes
+    rng = np.random.default_rng(3)
+    X, Y, Z = 13, 11, 17
+    for C in (1, 2, 3, 4):
+        for dt in (torch.float32, torch.bfloat16):
+            acc = torch.zeros((X, Y, Z, C), device=DEV)
+            cnt = torch.zeros((X, Y, Z), device=DEV)
+            racc = torch.zeros((X, Y, Z, C))
+            rcnt = torch.zeros((X, Y, Z))
+            for (ox, oy, oz) in ((0, 0, 0), (3, 1, 5), (5, 3, 9), (3, 1, 5)):
+                z = torch.from_numpy(rng.standard_normal((2, 8, 8, 8, C)).astype(np.float32) * 3).to(dt)
+                zd = z.to(DEV).permute(0, 4, 1, 2, 3)
+                d = N.desc(zd)
+                N.check(N.lib.ru3d_predict_accumulate(ctypes.byref(d), N.dtype_code(dt), 1, N.ptr(acc), N.ptr(cnt),
+                                                      X, Y, Z, ox, oy, oz, N.stream()))
+                zz = z[1].float()
+                p = torch.sigmoid(zz) if C == 1 else torch.softmax(zz, dim=-1)
+                racc[ox:ox + 8, oy:oy + 8, oz:oz + 8] += p
+                rcnt[ox:ox + 8, oy:oy + 8, oz:oz + 8] += 1
+            assert torch.equal(cnt.cpu(), rcnt)
+            assert (acc.cpu() - racc).abs().max().item() < 1e-6
+            crop, size = (1, 0, 2), (11, 10, 14)
+            sl = tuple(slice(c, c + s) for c, s in zip(crop, size))
+            prob = torch.empty(size + (C,), device=DEV)
+            mask = torch.empty(size, dtype=torch.uint8, device=DEV)
+            for one_hot, out in ((1, prob), (0, mask)):
+                N.check(N.lib.ru3d_predict_merge(N.ptr(acc), N.ptr(cnt), X, Y, Z, C, *crop, *size, one_hot,
+                                                 N.ptr(out), N.stream()))
+            rp = (acc.cpu() / cnt.cpu()[..., None])[sl]
+            assert np.array_equal(prob.cpu().numpy(), rp.numpy(), equal_nan=True)
+            if C == 1:
+                with np.errstate(invalid="ignore"):
+                    rm = np.nan_to_num(np.round(rp[..., 0].numpy()), nan=0.0).astype(np.uint8)
+            else:
+                rm = torch.argmax(torch.softmax(rp, dim=-1), dim=-1).numpy().astype(np.uint8)
+            got = mask.cpu().numpy()
+            bad = got != rm
+            assert not (bad & (_margin(rp.numpy()) > 1e-6)).any()
+    # windows outside the volume and too many classes are refused, not launched
+    z = torch.zeros((1, 8, 8, 8, 2), device=DEV).permute(0, 4, 1, 2, 3)
+    d = N.desc(z)
+    acc = torch.zeros((8, 8, 8, 2), device=DEV)
+    cnt = torch.zeros((8, 8, 8), device=DEV)
+    assert N.lib.ru3d_predict_accumulate(ctypes.byref(d), N.F32, 0, N.ptr(acc), N.ptr(cnt), 8, 8, 8, 1, 0, 0,
+                                         N.stream()) != 0
+    assert N.lib.ru3d_predict_accumulate(ctypes.byref(d), N.F32, 1, N.ptr(acc), N.ptr(cnt), 8, 8, 8, 0, 0, 0,
+                                         N.stream()) != 0
+
+
+def test_predict_config2_patch_bf16_vs_fp32_masks():
+    """ResUnet3D(4,32,1,3), one 160x128x128 case, 128^3 windows, 2 steps per patch: the bf16 run's mask agrees
+    with the fp32 run's on > 99.9 % of the confident voxels (random-init weights put most voxels near a tie, trained weights
+    do not, so only voxels whose fp32 top-2 margin exceeds 0.05 are compared), both cover the same voxels, and the probabilities sum to 1 wherever a window reached."""
+    torch.manual_seed(0)
+    model = network.ResUnet3D(4, 32, 1, 3).to(DEV)
+    image = O.synth_image((160, 128, 128, 1), 99).numpy()
+    out = {}
+    for dt in (torch.float32, torch.bfloat16):
+        network.set_compute_dtype(model, dt)
+        out[dt] = T.predict_per_patch(image, model, 3, (128, 128, 128), 2, False, True, patch_batch=2)
+    p32, p16 = out[torch.float32], out[torch.bfloat16]
+    assert p32.shape == (160, 128, 128, 3)
+    assert np.array_equal(np.isnan(p32), np.isnan(p16))
+    ok = ~np.isnan(p32).any(axis=-1)
+    assert ok.mean() > 0.9
+    assert np.abs(p32[ok].sum(-1) - 1).max() < 1e-5
+    assert np.abs(p32[ok] - p16[ok]).max() < 0.1
+    sure = ok & (_margin(p32) > 0.05)
+    agree = (p32[sure].argmax(-1) == p16[sure].argmax(-1)).mean()
+    print("bf16 vs fp32: max prob diff %.4f, confident voxels %.3f, agreement there %.5f"
+          % (np.abs(p32[ok] - p16[ok]).max(), sure.mean(), agree))
+    assert agree > 0.999, agree

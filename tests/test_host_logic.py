@@ -217,3 +217,42 @@ def test_deferred_sync_gives_same_means(tmp_path):
     lb = b._loader(list(range(8)), None, None, False)
     ra, rb = a.batch_loop(la), b.batch_loop(lb)
     assert ra.keys() == rb.keys() and abs(ra["loss"] - rb["loss"]) < 1e-6
+
+
+def test_sliding_window_plan_matches_numpy_integer_arange():
+    """inference.window_centres restates np.arange(start, end + 1e-8, step, dtype=int) (reference
+    trainer.py:38-40, np.int == int): same centres for every length/patch/step combination tried, every
+    window inside the padded volume."""
+    import inference as I
+    from oracle import unet_oracle as O
+    for patch in (8, 16, 80, 96, 128, 240):
+        for spp in (1, 2, 3, 4, 5):
+            for length in list(range(patch, patch + 40)) + [2 * patch, 3 * patch + 1, 512, 517]:
+                if length < patch:
+                    continue
+                start, end = patch // 2, length - patch // 2
+                num_steps = np.ceil((end - start) / (patch / spp))
+                step = np.array([(end - start) / (num_steps + 1e-8)])
+                step[step == 0] = 9999999
+                want = np.arange(np.int64(start), np.int64(end) + 1e-8, step[0], dtype=int).tolist()
+                got = I.window_centres(length, patch, spp)
+                assert got == want, (length, patch, spp, got, want)
+                assert got[0] - patch // 2 == 0 and got[-1] + patch // 2 <= length
+    # pad / crop offsets against crop_pad's box arithmetic, incl. the odd-difference one-voxel shift
+    for orig, patch in ((11, 16), (12, 16), (16, 16), (21, 16), (1, 96)):
+        full = I.padded_shape((orig,) * 3, (patch,) * 3)[0]
+        ramp = np.arange(1, orig + 1, dtype=np.float32)
+        padded = O.center_crop_pad(ramp, [full])
+        lo = I.pad_offset((orig,) * 3, (full,) * 3)[0]
+        assert padded.shape == (full,) and padded[lo] == 1 and (lo == 0 or padded[lo - 1] == 0)
+        back = O.center_crop_pad(padded, [orig])
+        co = I.crop_offset((orig,) * 3, (full,) * 3)[0]
+        assert np.array_equal(back, padded[co:co + orig])
+    assert T.predict_per_patch is I.predict_per_patch
+
+
+def test_predict_per_patch_refuses_cpu_model_and_odd_patch():
+    import inference as I
+    model = network.ResUnet3D(1, 4, 1, 2)
+    with pytest.raises(N.Ru3dError):
+        I.predict_per_patch(np.zeros((8, 8, 8, 1), np.float32), model, 2, (8, 8, 8), 2, False)

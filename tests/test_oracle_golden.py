@@ -222,3 +222,31 @@ def test_naive_primitives_pin_torch_conv():
     bt = torch.randn(5, generator=g)
     ref = torch.nn.functional.conv_transpose3d(x, wt, bt, stride=2, padding=1).numpy()
     assert np.abs(O.conv_transpose3d_naive(x, wt, bt) - ref).max() < 1e-4
+
+
+# --------------------------------------------------------------------------- G6: sliding-window inference
+def _g6_case(g, tag):
+    image = g[tag + "/image"]
+    patch = tuple(int(v) for v in g[tag + "/patch"])
+    spp, pool, feat, ncls = (int(v) for v in g[tag + "/meta"])
+    w = {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "/w/")}
+    return image, patch, spp, pool, ncls, w
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_g6_predict_per_patch_matches_reference(golden_dir, tag):
+    """trainer.predict_per_patch restated on the oracle forward: identical masks, identical NaN pattern of the
+    never-visited border, probabilities within 2e-6 (fp32 softmax sums of <= 24 windows)."""
+    g = np.load(os.path.join(golden_dir, "g6_predict.npz"))
+    image, patch, spp, pool, ncls, w = _g6_case(g, tag)
+    mask, _ = O.predict_per_patch(image, w, pool, ncls, patch, spp, False)
+    prob, _ = O.predict_per_patch(image, w, pool, ncls, patch, spp, True)
+    gm, gp = g[tag + "/mask"], g[tag + "/prob"]
+    assert mask.dtype == np.uint8 and mask.shape == gm.shape == image.shape[:3]
+    assert np.array_equal(mask, gm)
+    assert prob.dtype == np.float32 and prob.shape == gp.shape
+    assert np.array_equal(np.isnan(prob), np.isnan(gp))
+    assert np.nanmax(np.abs(prob - gp)) < 2e-6
+    if tag in "abd":
+        assert np.isnan(gp).any()          # the quirk is really in the fixture: part of the far border is never visited
+        assert (gm[np.isnan(gp).any(axis=-1)] == 0).all()
