@@ -3,6 +3,7 @@ Functions that stitch them into the reference's blocks.  No arithmetic happens h
 tensor value is produced by a HIP kernel of libru3d.so; torch supplies memory and the tape.
 """
 import ctypes
+import os
 import threading
 
 import torch
@@ -338,6 +339,57 @@ def as_grad(g, like_dtype):
     return N.to_ndhwc(g)
 
 
+# --------------------------------------------------------------------------- second stream for weight gradients
+# Inside one block's backward the weight gradient of a conv and its input gradient are independent: the wgrad
+# launches (kernel + fixed-order slab reduce) go to a second HIP stream and run beside the dgrad -> InstanceNorm
+# backward chain on the main stream.  On the deep levels (8^3 / 16^3 voxels) neither side fills 256 CUs alone.
+# The join is inside the same backward, so autograd, GradSync hooks and the optimizer only ever see finished
+# gradients on the main stream.  Off by default (RU3D_WGRAD_STREAM=1 enables): at ~550 launches per 28 ms step the extra stream switches cost
+# the host more than the overlap returns; it is kept for graph-captured steps.
+_USE_SIDE = os.environ.get("RU3D_WGRAD_STREAM", "0") == "1"
+_SIDE = {}
+
+
+def _side_stream(device):
+    s = _SIDE.get(device)
+    if s is None:
+        s = _SIDE[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+class _OnSide:
+    """`with _OnSide(device):` - the body's launches are ordered after everything already on the current stream
+    and run on the side stream; `join()` makes the current stream wait for them."""
+
+    def __init__(self, device):
+        self.device = device
+        self.ctx = None
+
+    def __enter__(self):
+        if _USE_SIDE:
+            side = _side_stream(self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            self.ctx = None
+        return False
+
+
+def _join(device, *outs):
+    if not _USE_SIDE:
+        return
+    cur = torch.cuda.current_stream(device)
+    cur.wait_stream(_side_stream(device))
+    for t in outs:
+        if t is not None:
+            t.record_stream(cur)
+
+
 # --------------------------------------------------------------------------- autograd: plain conv (stem / head / skip)
 class ConvFn(torch.autograd.Function):
     """nn.Conv3d(k in {1,3}, stride in {1,2}, padding=k//2) with bias: reference network.py:541-547 (stem, head)."""
@@ -364,14 +416,16 @@ class ConvFn(torch.autograd.Function):
         sd = ctx.storage_dtype
         gy = as_grad(gy, sd)
         gx = gw = gb = None
-        if ctx.needs_input_grad[1]:
-            gw = conv_wgrad(xin, gy, ctx.k, ctx.stride)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = channel_sum(gy)
+        with _OnSide(gy.device):
+            if ctx.needs_input_grad[1]:
+                gw = conv_wgrad(xin, gy, ctx.k, ctx.stride)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = channel_sum(gy)
         if ctx.needs_input_grad[0]:
             gx = conv_dgrad(gy, pwd, tuple(xin.shape), ctx.k, ctx.stride)
             if gx.dtype != ctx.in_dtype:
                 gx = gx.to(ctx.in_dtype)
+        _join(gy.device, gw, gb)
         return gx, gw, gb, None, None, None
 
 
@@ -421,27 +475,32 @@ class ResBlockFn(torch.autograd.Function):
     def backward(ctx, gz):
         x, y1, a1, y2, z, mean1, scale1, mean2, scale2, pw2d, pw1d, pwsd = ctx.saved_tensors
         sd = x.dtype
+        dev = x.device
         stride = ctx.stride
         gz = as_grad(gz, sd)
         # lrelu(IN(y2) + skip): dy2 and the pre-activation gradient (= d/dskip)
         dy2, gpre = in_lrelu_bwd(gz, z, y2, mean2, scale2, want_gpre=True)
-        gw2 = conv_wgrad(a1, dy2, 3, 1)
+        gws = gbs = None
+        with _OnSide(dev):
+            gw2 = conv_wgrad(a1, dy2, 3, 1)
+            if ctx.has_skip_conv:
+                gws = conv_wgrad(x, gpre, 1, stride)
+                gbs = channel_sum(gpre)
         gb2 = None   # a bias that feeds InstanceNorm has an identically zero gradient: reported as "no gradient"
         da1 = conv_dgrad(dy2, pw2d, tuple(a1.shape), 3, 1)
         dy1, _ = in_lrelu_bwd(da1, a1, y1, mean1, scale1)
-        gw1 = conv_wgrad(x, dy1, 3, stride)
+        with _OnSide(dev):
+            gw1 = conv_wgrad(x, dy1, 3, stride)
         gb1 = None
-        gws = gbs = None
         gx = None
         need_gx = ctx.needs_input_grad[0]
         if ctx.has_skip_conv:
-            gws = conv_wgrad(x, gpre, 1, stride)
-            gbs = channel_sum(gpre)
             if need_gx:
                 gx0 = conv_dgrad(gpre, pwsd, tuple(x.shape), 1, stride)
                 gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gx0)
         elif need_gx:
             gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gpre)
+        _join(dev, gw1, gw2, gws, gbs)
         return gx, gw1, gb1, gw2, gb2, gws, gbs, None, None
 
 
@@ -493,9 +552,11 @@ class UpFn(torch.autograd.Function):
         gu = g[:, :cout] if ctx.has_skip else g
         gskip = g[:, cout:] if ctx.has_skip else None
         dy, _ = in_lrelu_bwd(gu, u, y, mean, scale, zero_far=True)
-        gw = convt_wgrad(x, dy)
-        gb = channel_sum(dy)
+        with _OnSide(x.device):
+            gw = convt_wgrad(x, dy)
+            gb = channel_sum(dy)
         gx = None
         if ctx.needs_input_grad[0]:
             gx = convt_dgrad(dy, pwd, tuple(x.shape))
+        _join(x.device, gw, gb)
         return gx, gw, gb, gskip

@@ -173,10 +173,48 @@ int pack_generic_launch(const float* src, void* dst, int cin, int cout, int taps
 
 // Batched packing: blockIdx.y selects the weight, both packed layouts are produced by the same kernel
 // (MFMA fragment order: see conv_mfma.hip; generic: [tap][cin][cout_pad]).
+//
+// MFMA items whose source has one of the two contiguous-weight shapes (s_i == taps: [co][ci][tap], the forward
+// roles; s_o == taps: [ci][co][tap] seen from the packed side, the input-gradient roles) are transposed through
+// LDS: a block owns one (32 co) x (16 ci) fragment column for every tap, reads its source rows as contiguous runs
+// (16*taps or 32*taps floats) and writes one 1-KiB fragment per tap.  The element-wise gather it replaces touched a
+// different 64-byte line with every 4-byte read.
+#define PACK_TILE_FLOATS (32 * (16 * 27 + 1))   // >= 16 * (32 * 27 + 1)
 template <typename T>
 __global__ __launch_bounds__(256) void pack_batch_kernel(PackBatch b) {
+    __shared__ float tile[PACK_TILE_FLOATS];   // 32 rows of 16*taps(+1) floats, or 16 rows of 32*taps(+1)
     const PackOne& p = b.item[blockIdx.y];
     T* dst = (T*)p.dst;
+    const int taps = p.taps;
+    const bool rows_co = (p.s_i == taps), rows_ci = (p.s_o == taps);
+    if (p.mfma && sizeof(T) == 2 && taps <= 27 && (rows_co || rows_ci)) {
+        const int KS = p.cin / 16, NTT = p.cout / 32;
+        const int nrows = rows_co ? 32 : 16, rowlen = (rows_co ? 16 : 32) * taps, pitch = rowlen + 1;
+        for (int unit = blockIdx.x; unit < KS * NTT; unit += gridDim.x) {
+            const int ks = unit / NTT, nt = unit % NTT;
+            const float* base = p.src + (int64_t)(nt * 32) * p.s_o + (int64_t)(ks * 16) * p.s_i;
+            const int64_t row_stride = rows_co ? p.s_o : p.s_i;
+            __syncthreads();
+            for (int e = threadIdx.x; e < nrows * rowlen; e += 256) {
+                const int r = e / rowlen, j = e - r * rowlen;
+                tile[r * pitch + j] = base[(int64_t)r * row_stride + j];
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < taps * 64; e += 256) {
+                const int tap = e >> 6, lane = e & 63;
+                const int co = lane & 31, ci0 = 8 * (lane >> 5);
+                bf16x8 v;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int ci = ci0 + j;
+                    const float f = rows_co ? tile[co * pitch + ci * taps + tap] : tile[ci * pitch + co * taps + tap];
+                    v[j] = (bf16)f;
+                }
+                *reinterpret_cast<bf16x8*>((bf16*)p.dst + ((((int64_t)tap * KS + ks) * NTT + nt) * 64 + lane) * 8) = v;
+            }
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < p.total; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         if (p.mfma) {
@@ -338,9 +376,72 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// The same sum for the wide layers (Cin*Cout >= 128*128: few slabs, megabytes each), where the write side
+// matters: slabs are [tap][ci][co] but dw is [co][ci][tap] (Conv3d) or [ci][co][tap] (ConvTranspose3d), so the
+// kernel above stores 4 bytes per 108-byte stride.  Here a block owns all taps of a (4 ci) x (32 co) tile, sums
+// the slabs in slab order (deterministic) with 128-byte row reads, transposes through LDS and writes runs of
+// 4*taps (CO_MAJOR, Conv3d) or 32*taps (ConvTranspose3d) consecutive floats.
+template <bool CO_MAJOR>
+__global__ __launch_bounds__(256) void wgrad_reduce_tiled_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                 int chunks, int taps, int cin, int cout, int64_t s_o,
+                                                                 int64_t s_i) {
+    __shared__ float tile[32 * (4 * 27 + 1)];
+    const int cot = blockIdx.x % (cout / 32), cit = blockIdx.x / (cout / 32);
+    const int ci0 = cit * 4, co0 = cot * 32;
+    const int64_t total = (int64_t)taps * cin * cout;
+    const int nquads = taps * 32;   // (tap, ci_l, co4)
+    const int pitch_co = 4 * taps + 1;
+#pragma unroll 1
+    for (int qid = threadIdx.x; qid < nquads; qid += 256) {
+        const int tap = qid >> 5, ci_l = (qid >> 3) & 3, co4 = qid & 7;
+        const float* src = part + ((int64_t)tap * cin + ci0 + ci_l) * cout + co0 + co4 * 4;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+        int c = 0;
+        for (; c + 3 < chunks; c += 4) {
+            s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)c * total);
+            s1 += *reinterpret_cast<const f32x4*>(src + (int64_t)(c + 1) * total);
+            s2 += *reinterpret_cast<const f32x4*>(src + (int64_t)(c + 2) * total);
+            s3 += *reinterpret_cast<const f32x4*>(src + (int64_t)(c + 3) * total);
+        }
+        for (; c < chunks; c++) s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)c * total);
+        const f32x4 s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int co = co4 * 4 + e;
+            if (CO_MAJOR) tile[co * pitch_co + ci_l * taps + tap] = s[e];
+            else tile[ci_l * (32 * taps + 1) + co * taps + tap] = s[e];
+        }
+    }
+    __syncthreads();
+    if (CO_MAJOR) {
+        const int run = 4 * taps;     // dw[(co0+co)*s_o + ci0*taps + j], j < run
+        for (int e = threadIdx.x; e < 32 * run; e += 256) {
+            const int co = e / run, j = e - co * run;
+            dw[(int64_t)(co0 + co) * s_o + (int64_t)ci0 * s_i + j] = tile[co * pitch_co + j];
+        }
+    } else {
+        const int run = 32 * taps;    // dw[(ci0+ci)*s_i + co0*taps + j], j < run
+        for (int e = threadIdx.x; e < 4 * run; e += 256) {
+            const int ci = e / run, j = e - ci * run;
+            dw[(int64_t)(ci0 + ci) * s_i + (int64_t)co0 * s_o + j] = tile[ci * (run + 1) + j];
+        }
+    }
+}
+
 int wgrad_reduce_launch(const float* part, float* dw, int chunks, int taps, int cin, int cout, int64_t s_o, int64_t s_i,
                         hipStream_t st) {
     const int64_t total = (int64_t)taps * cin * cout;
+    if ((int64_t)cin * cout >= 128 * 128 && (cin % 4) == 0 && (cout % 32) == 0 && taps <= 27 &&
+        (s_i == taps || s_o == taps)) {
+        const unsigned blocks = (unsigned)((cin / 4) * (cout / 32));
+        if (s_i == taps)
+            hipLaunchKernelGGL(wgrad_reduce_tiled_kernel<true>, dim3(blocks), dim3(256), 0, st, part, dw, chunks, taps,
+                               cin, cout, s_o, s_i);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_tiled_kernel<false>, dim3(blocks), dim3(256), 0, st, part, dw, chunks, taps,
+                               cin, cout, s_o, s_i);
+        return ru3d_check_launch("wgrad_reduce_tiled");
+    }
     const int64_t blocks = (total + 255) / 256;
     if (blocks > 0x7fffffff) return ru3d_fail(-1, "wgrad_reduce: grid too large");
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, dw, chunks, taps, cin, cout,

@@ -18,13 +18,19 @@ struct ChanLoop {
     int chunks; // blocks along the voxel axis
 };
 
-static ChanLoop make_chanloop(int64_t V, int C, int vec, int max_iters) {
+static ChanLoop make_chanloop(int64_t V, int C, int vec, int max_iters, int N = 1) {
     ChanLoop cl;
     cl.V = (int)V;
     cl.G = C / vec;
     cl.Gb = cl.G < 256 ? cl.G : 256;
     cl.vpb = 256 / cl.Gb;
-    int64_t span = (int64_t)cl.vpb * max_iters;
+    // small tensors (the deep levels: 8^3 .. 16^3 voxels, hundreds of channels): shorten the per-thread loop until
+    // the launch has ~2048 blocks, otherwise a handful of blocks walk the tensor serially at load latency
+    const int64_t gz = (cl.G + cl.Gb - 1) / cl.Gb;
+    int64_t iters = (V * N * gz + (int64_t)cl.vpb * 2048 - 1) / ((int64_t)cl.vpb * 2048);
+    if (iters < 4) iters = 4;
+    if (iters > max_iters) iters = max_iters;
+    int64_t span = (int64_t)cl.vpb * iters;
     int64_t chunks = (V + span - 1) / span;
     if (chunks > 4096) {
         chunks = 4096;
@@ -362,7 +368,7 @@ static int stats_impl(const ru3d_tensor* y, const float* drop, float* mean, floa
                       hipStream_t st) {
     const int64_t V = (int64_t)y->d * y->h * y->w;
     const int vec = pick_vec<T>(y->c, {y});
-    ChanLoop cl = make_chanloop(V, y->c, vec, 64);
+    ChanLoop cl = make_chanloop(V, y->c, vec, 64, y->n);
     dim3 grid(cl.chunks, y->n, (cl.G + cl.Gb - 1) / cl.Gb);
     double* part = (double*)ws;
 #define CALL(TT, VV)                                                                                              \
@@ -395,7 +401,7 @@ static int in_fwd_impl(const ru3d_tensor* y, const float* mean, const float* sca
                        const ru3d_tensor* out, float slope, hipStream_t st) {
     const int64_t V = (int64_t)y->d * y->h * y->w;
     const int vec = pick_vec<T>(y->c, {y, res, out});
-    ChanLoop cl = make_chanloop(V, y->c, vec, 16);
+    ChanLoop cl = make_chanloop(V, y->c, vec, 16, y->n);
     dim3 grid(cl.chunks, y->n, (cl.G + cl.Gb - 1) / cl.Gb);
 #define CALL(TT, VV)                                                                                               \
     if (res)                                                                                                       \
@@ -426,7 +432,7 @@ static int in_bwd_impl(const ru3d_tensor* gout, const ru3d_tensor* out, const ru
                        int zero_far, hipStream_t st) {
     const int64_t V = (int64_t)y->d * y->h * y->w;
     const int vec = pick_vec<T>(y->c, {gout, out, y, dy, gpre});
-    ChanLoop cl = make_chanloop(V, y->c, vec, 64);
+    ChanLoop cl = make_chanloop(V, y->c, vec, 64, y->n);
     dim3 grid(cl.chunks, y->n, (cl.G + cl.Gb - 1) / cl.Gb);
     double* part = (double*)ws;
     const int NC = y->n * y->c;
@@ -447,7 +453,7 @@ static int in_bwd_impl(const ru3d_tensor* gout, const ru3d_tensor* out, const ru
                        y->c, NC, 1.0 / (double)V, m12);
     rc = ru3d_check_launch("in_lrelu_bwd_finalize");
     if (rc) return rc;
-    ChanLoop ca = make_chanloop(V, y->c, vec, 16);
+    ChanLoop ca = make_chanloop(V, y->c, vec, 16, y->n);
     dim3 grida(ca.chunks, y->n, (ca.G + ca.Gb - 1) / ca.Gb);
 #define CALL(TT, VV)                                                                                                  \
     if (gpre)                                                                                                         \
@@ -487,7 +493,7 @@ template <typename T>
 static int chansum_impl(const ru3d_tensor* t, float* out, void* ws, hipStream_t st) {
     const int64_t V = (int64_t)t->d * t->h * t->w;
     const int vec = pick_vec<T>(t->c, {t});
-    ChanLoop cl = make_chanloop(V, t->c, vec, 64);
+    ChanLoop cl = make_chanloop(V, t->c, vec, 64, t->n);
     dim3 grid(cl.chunks, t->n, (cl.G + cl.Gb - 1) / cl.Gb);
     double* part = (double*)ws;
 #define CALL(TT, VV)                                                                                              \
@@ -516,7 +522,7 @@ template <typename T>
 static int copy_add_impl(const ru3d_tensor* a, const ru3d_tensor* b, const ru3d_tensor* dst, hipStream_t st) {
     const int64_t V = (int64_t)a->d * a->h * a->w;
     const int vec = pick_vec<T>(a->c, {a, b, dst});
-    ChanLoop cl = make_chanloop(V, a->c, vec, 16);
+    ChanLoop cl = make_chanloop(V, a->c, vec, 16, a->n);
     dim3 grid(cl.chunks, a->n, (cl.G + cl.Gb - 1) / cl.Gb);
 #define CALL(TT, VV)                                                                                                 \
     if (b)                                                                                                           \
