@@ -66,6 +66,14 @@ size_t wgrad_mfma_ws_bytes(const WgradGeom& g);
 int wgrad_mfma_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, WgradGeom g,
                       hipStream_t st);
 
+// conv_slide.hip (3x3x3 stride-1, 32 -> 32 channels: D-sliding plane ring, weights resident in LDS)
+struct SlidePlan {
+    int dsplit, DL, tiles_h, tiles_w, units, grid;
+};
+bool slide_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* out);
+int conv_slide_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
+                      float* stat_slab, hipStream_t st);
+
 // small_convs.hip (1-channel stem, 2..4-channel head)
 bool stem_fwd_eligible(const ConvGeom& g, int dtype, int y_dtype, const void* res);
 int stem_fwd_launch(const void* x, const void* w, const float* bias, void* y, const ConvGeom& g, int dtype,

@@ -593,10 +593,19 @@ static int launch_s1_auto(const MfmaConvArgs& a, hipStream_t st) {
 // Fused InstanceNorm statistics (producer/consumer kernel only): slab[workgroup][wave][n][cout_local][2] floats.
 bool mfma_conv_can_fuse_stats(const ConvGeom& g) {
     if (!(g.k == 3 && g.stride == 1 && !g.transposed && (g.Cin % 32) == 0 && (g.Cout % 32) == 0)) return false;
+    SlidePlan sp;
+    if (slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) return true;
     return s1_plan(g.N, g.Do, g.Ho, g.Wo, g.Cout).pc;
 }
 
 static void stats_slab_geom(const ConvGeom& g, int* gx, int* gy, int* cb) {
+    SlidePlan sp;
+    if (slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) {
+        *gx = sp.grid;
+        *gy = 1;
+        *cb = 32;
+        return;
+    }
     const S1Plan p = s1_plan(g.N, g.Do, g.Ho, g.Wo, g.Cout);
     pc_grid(g.Cout, p.nt2, p.nblk_pc, gx, gy);
     *cb = p.nt2 ? 64 : 32;
@@ -853,6 +862,12 @@ int conv_mfma_launch(const void* x, const void* w, const float* bias, const void
     if (!(g.k == 3 && g.stride == 1 && !g.transposed && (g.Cin % 32) == 0)) {
         if (stat_slab) return ru3d_fail(-1, "conv_mfma: fused statistics not available for this form");
         return launch_direct(x, w, bias, res, y, g, st);
+    }
+    {
+        SlidePlan sp;
+        if ((g.ldy % 8) == 0 && (!res || (g.ldr % 8) == 0) && aligned_to(y, 16) && (!res || aligned_to(res, 16)) &&
+            slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp))
+            return conv_slide_launch(x, w, bias, res, y, g, stat_slab, st);
     }
     MfmaConvArgs a;
     a.x = (const bf16*)x;
