@@ -3,20 +3,22 @@
 //
 // The halo-tile kernels of conv_mfma.hip re-read every input voxel ~3.2x (2x4x32 tile, 1-voxel halo on six faces)
 // and stream the 55 KB weight once per tile; both arrive through the same ~10 B/clk/CU path and that, not the
-// MFMA pipe, set their time.  This kernel removes both re-reads:
-//   * the whole 32x32x27 weight lives in LDS (fragment order, 55 KB) for the life of the persistent workgroup;
+// MFMA pipe, set their time.  This kernel removes both re-reads and most of the LDS traffic:
+//   * the whole 32x32x27 weight lives in REGISTERS: 54 fragments x 4 VGPRs per lane, loaded once per persistent
+//     workgroup (one wave per SIMD, 512 registers) - no weight bytes move after the prologue;
 //   * a workgroup owns an (8 x 32) column in (H, W) and SLIDES along D: a ring of 4 input planes (10 x 34 halo
 //     rows x 64 B) stays in LDS, each step loads ONE new plane (21.8 KB) for 256 output voxels - 1.33x
-//     amplification instead of 3.2x, and it is loaded while the step's 432 MFMAs run (global -> registers at
-//     the top of the step, registers -> LDS at the bottom, one barrier per step).
-// LDS rows are 64 bytes with the 16-byte piece index XOR-ed by ((row >> 2) & 3): any 16 rows that are distinct
-// mod 16 - which is what every ds_read_b128 lane group of a 32-voxel W-run touches - land in 16 distinct bank
-// quads, for every tap shift.
-// Per step and wave: 54 (tap, k-step) iterations x [1 weight fragment + 2 activation fragments from LDS, 2 MFMAs].
+//     amplification instead of 3.2x - while the step's 432 MFMAs run (global -> registers at the top of the step,
+//     registers -> LDS behind the step's barrier);
+//   * a wave computes two output rows (h, h+1); their taps kh = 0..2 touch only 4 distinct input rows, so a
+//     (kd, kw, k-step) group issues 4 activation-fragment reads for 6 MFMAs (0.67 KB of LDS reads per MFMA,
+//     a third of the LDS array's rate at full MFMA speed).
+// LDS rows are 80 bytes (64 B of channels + 16 B pad): conflict-free for the ds_read_b128 of a 32-voxel W-run, and
+// every fragment address is one per-lane base plus a compile-time offset (no address registers per tap).
 // The step is software-pipelined across planes: the epilogue of plane s (bf16 conversion, LDS transpose, statistics,
 // stores) is issued between the MFMAs of plane s+1 (two accumulator sets), the fragment ring runs on into the next
-// step, and the single barrier of a step sits before iteration 33 - only the kd = 2 taps (iterations 36..53) read
-// the newest plane, so its LDS store (behind the previous step's barrier) has a third of a step to land.
+// step, and the single barrier of a step sits two groups before the kd = 2 taps - only they read the newest
+// plane, so its LDS store (behind the previous step's barrier) has two thirds of a step to land.
 #include "common.h"
 #include "conv.h"
 
@@ -25,15 +27,17 @@
 namespace {
 constexpr int TH = 8, TW = 32, HH = TH + 2, WW = TW + 2;
 constexpr int PROWS = HH * WW;        // 340 halo rows per plane
-constexpr int PLANE = PROWS * 32;     // bf16 elements per plane
+constexpr int PITCH = 40;             // bf16 elements per staged row: 64 B of channels + 16 B pad (conflict-free
+                                      // ds_read_b128 over a 32-voxel W-run, and every fragment address is affine)
+constexpr int PLANE = PROWS * PITCH;  // bf16 elements per plane
 constexpr int RING = 4;
-constexpr int WTS = 54 * 64 * 8;      // 27 taps x 2 k-steps x 64 lanes x 8 bf16
 constexpr int WAVE_ROWS = PROWS / 4;  // 85 rows of a plane are staged by each wave
-constexpr int EST_PITCH = 40;         // bf16 elements per epilogue-patch row (80 bytes)
-constexpr int XD = 3;                 // LDS fragment prefetch depth (iterations)
+constexpr int EST_PITCH = 36;         // floats per epilogue-patch row (32 channels + 4 pad = 144 bytes)
+constexpr int XG = 2;                 // fragment ring depth in groups (prefetch XG - 1 groups ahead)
+constexpr int NG = 18;                // (kd, kw, k-step) groups per step, 6 MFMAs each
 constexpr int NSTG = 6;               // 16-byte pieces staged per thread and plane (85 rows x 4 pieces / 64 lanes)
 static_assert(PROWS % 4 == 0, "plane rows split evenly over 4 waves");
-static_assert((RING * PLANE + WTS + 4 * 64 * EST_PITCH) * 2 <= 160 * 1024, "LDS budget");
+static_assert(RING * PLANE * 2 + 4 * 64 * EST_PITCH * 4 <= 160 * 1024, "LDS budget");
 
 struct SlideArgs {
     const bf16* x;
@@ -46,6 +50,9 @@ struct SlideArgs {
     int ldx, ldy, ldr;
     int flip;
     int tiles_h, tiles_w, dsplit, DL, units;
+#ifdef RU3D_SLIDE_STAMPS
+    long long* stamps;
+#endif
 };
 
 template <int I, int N, typename F>
@@ -56,21 +63,51 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-__device__ __forceinline__ int piece_off(int row, int piece) { return row * 32 + ((piece ^ ((row >> 2) & 3)) << 3); }
+// MFMA with the operand register classes pinned: accumulators and (most) weight fragments live in the AGPR half of
+// the 512-register file, activation fragments arrive from LDS in VGPRs.  Left to itself the allocator parks the
+// weights in AGPRs too but copies each fragment back to VGPRs before use (4 v_accvgpr_read per MFMA).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <bool WA, bool ZERO>
+__device__ __forceinline__ void mfma_w(f32x16& acc, const bf16x8& w, const bf16x8& x) {
+    const i32x4 wi = __builtin_bit_cast(i32x4, w), xi = __builtin_bit_cast(i32x4, x);
+    if constexpr (ZERO) {
+        if constexpr (WA) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "a"(wi), "v"(xi));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(wi), "v"(xi));
+    } else {
+        if constexpr (WA) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(wi), "v"(xi));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(wi), "v"(xi));
+    }
+}
+constexpr int WA_FRAGS = 48;          // weight fragments held in AGPRs (48 x 4 + 64 accumulator registers = 256)
 
+__device__ __forceinline__ int piece_off(int row, int piece) { return row * PITCH + piece * 8; }
+
+// HAS_RES / HAS_STATS are compile-time: a residual load that is only conditionally issued still makes the compiler
+// guard every reuse of its destination registers with a vmcnt wait, and vmcnt retires in order - in the plain
+// variant those waits landed on the plane loads that had just been issued (an HBM latency per step).
+template <bool HAS_RES, bool HAS_STATS>
 __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16 lds[RING * PLANE + WTS + 4 * 64 * EST_PITCH];
-    bf16* wts = lds + RING * PLANE;
+    __shared__ __attribute__((aligned(16))) bf16 lds[RING * PLANE];
+    __shared__ __attribute__((aligned(16))) float est_s[4 * 64 * EST_PITCH];   // fp32 epilogue patches, one per wave
     const int tid = threadIdx.x, lane = tid & 63;
+#ifdef RU3D_SLIDE_STAMPS
+    __shared__ long long stamp_s[4 * 24];
+#define SLIDE_STAMP(ph, g, s) \
+    if ((s) >= 8 && (s) < 12 && tid == 0) stamp_s[(ph) * 24 + (g)] = clock64();
+#else
+#define SLIDE_STAMP(ph, g, s)
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- weights -> LDS once (the input-gradient role reads the taps mirrored: done here, not in the loop)
-    for (int c = tid; c < 54 * 64; c += 256) {
-        const int frag = c >> 6, ln = c & 63;
-        const int tap = frag >> 1, ks = frag & 1;
+    // ---- the weight: fragment (tap, ks) of this lane, all 54 of them (the input-gradient role reads the taps
+    // mirrored: applied here, not in the loop)
+    bf16x8 wreg[54];
+    static_for<0, 54>([&](auto fc) {
+        constexpr int f = decltype(fc)::value;
+        constexpr int tap = f >> 1, ks = f & 1;
         const int st = a.flip ? 26 - tap : tap;
-        *reinterpret_cast<bf16x8*>(wts + c * 8) = a.w[(st * 2 + ks) * 64 + ln];
-    }
+        wreg[f] = a.w[(st * 2 + ks) * 64 + lane];
+    });
 
     // ---- staging constants: this thread's pieces of the wave's 85 plane rows
     int srel[NSTG], sdst[NSTG], szh[NSTG], szw[NSTG];
@@ -84,31 +121,16 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
         srel[i] = ((r / WW) * a.W + (r % WW)) * a.ldx + part * 8;
         sdst[i] = piece_off(r, part);
     }
-    // ---- fragment offsets of this lane: output rows 2*wave + m, voxel (lane & 31) of the W-run, k-half lane >> 5
-    int boff[2][3][3][2];
-#pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-        for (int kh = 0; kh < 3; kh++)
-#pragma unroll
-            for (int kw = 0; kw < 3; kw++)
-#pragma unroll
-                for (int ks = 0; ks < 2; ks++)
-                    boff[m][kh][kw][ks] = piece_off((2 * wave + m + kh) * WW + (lane & 31) + kw, 2 * ks + (lane >> 5));
-    const bf16* wl = wts + lane * 8;
-
-    f32x4 bq[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        bq[q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + 8 * q + 4 * (lane >> 5)) : z4;
-    }
+    // ---- fragment address of this lane: input row 2*wave (+ r = 0..3: the rows that serve output rows 2*wave and
+    // 2*wave + 1), voxel (lane & 31) of the W-run (+ kw), k-half lane >> 5 (+ 2 per k-step); everything in
+    // parentheses is a compile-time offset
+    const bf16* bl = lds + piece_off((2 * wave) * WW + (lane & 31), lane >> 5);
 
     // fused InstanceNorm statistics (same slab layout as the producer/consumer kernel: [workgroup][wave][n][32][2])
     float st1[8], st2[8];
     int cur_n = -1;
     auto stat_flush = [&]() {
-        if (!a.stat_slab || cur_n < 0) return;
+        if (!HAS_STATS || cur_n < 0) return;
         float* dst = a.stat_slab + ((((int64_t)blockIdx.x * 4 + wave) * a.N + cur_n) * 32) * 2;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -127,8 +149,12 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
     };
 
     f32x16 acc[2][2];   // [step parity][output row of the wave]
-    bf16x8 aq[XD], xq[XD][2];
-    bf16* est = lds + RING * PLANE + WTS + wave * (64 * EST_PITCH);
+    bf16x8 xq[XG][4];   // activation fragments of XG groups: input rows 2*wave .. 2*wave + 3
+    float* est = est_s + wave * (64 * EST_PITCH);
+    // bias of the 8 channels this lane stores in the row phase of the epilogue
+    float bias8[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) bias8[i] = a.bias ? a.bias[(lane & 3) * 8 + i] : 0.f;
 
     const int G = gridDim.x;
     const bool remap = (a.units % 8) == 0 && (G % 8) == 0;
@@ -143,87 +169,96 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
         const int n = u / a.dsplit;
         const int d0 = dc * a.DL, h0 = th_i * TH, w0 = tw_i * TW;
 
+        // Plane loads are issued unconditionally (out-of-range pieces read the first bytes of the plane) and zeroed
+        // when they are written to LDS a step later: a select on the loaded value at issue time would make the wave
+        // wait for HBM right there.
         bool ok[NSTG];
+        int soff[NSTG];
+        const int base_hw = ((h0 - 1) * a.W + (w0 - 1)) * a.ldx;
 #pragma unroll
         for (int i = 0; i < NSTG; i++) {
             const int gh = h0 - 1 + szh[i], gw = w0 - 1 + szw[i];
             ok[i] = gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+            soff[i] = ok[i] ? base_hw + srel[i] : 0;
         }
         const int64_t plane_stride = (int64_t)a.H * a.W * a.ldx;
-        const int64_t base0 = (((int64_t)n * a.D) * a.H + (h0 - 1)) * (int64_t)a.W * a.ldx + (int64_t)(w0 - 1) * a.ldx;
 
         auto load_plane = [&](int pr, bf16x8 (&stg)[NSTG]) {
+            int d = d0 - 1 + pr;
+            d = d < 0 ? 0 : (d >= a.D ? a.D - 1 : d);
+            const bf16* src = a.x + ((int64_t)n * a.D + d) * plane_stride;
+#pragma unroll
+            for (int i = 0; i < NSTG; i++) stg[i] = *reinterpret_cast<const bf16x8*>(src + soff[i]);
+        };
+        auto store_plane = [&](int pr, int slot, const bf16x8 (&stg)[NSTG]) {
             const int d = d0 - 1 + pr;
             const bool dok = d >= 0 && d < a.D;
-            const bf16* src = a.x + base0 + (int64_t)d * plane_stride;
 #pragma unroll
             for (int i = 0; i < NSTG; i++) {
-                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (dok && ok[i]) v = *reinterpret_cast<const bf16x8*>(src + srel[i]);
-                stg[i] = v;
+                const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (szh[i] >= 0) *reinterpret_cast<bf16x8*>(lds + slot * PLANE + sdst[i]) = (dok && ok[i]) ? stg[i] : z8;
             }
         };
-        auto store_plane = [&](int slot, const bf16x8 (&stg)[NSTG]) {
-#pragma unroll
-            for (int i = 0; i < NSTG; i++)
-                if (szh[i] >= 0) *reinterpret_cast<bf16x8*>(lds + slot * PLANE + sdst[i]) = stg[i];
-        };
 
-        __syncthreads();   // the previous unit has left the ring (first pass: nothing to wait for)
-        {
-            bf16x8 s0[NSTG], s1[NSTG], s2[NSTG];
-            load_plane(0, s0);
-            load_plane(1, s1);
-            load_plane(2, s2);
-            store_plane(0, s0);
-            store_plane(1, s1);
-            store_plane(2, s2);
-        }
+        __syncthreads();   // the previous unit has left the ring
+        bf16x8 stg[NSTG];   // the plane in flight: loaded behind one step's barrier, stored behind the next one's
+        load_plane(0, stg);
+        store_plane(0, 0, stg);
+        load_plane(1, stg);
+        store_plane(1, 1, stg);
+        load_plane(2, stg);
+        store_plane(2, 2, stg);
+        load_plane(3, stg);
         __syncthreads();
 
-        if (a.stat_slab && n != cur_n) {
+        if (HAS_STATS && n != cur_n) {
             stat_flush();
             cur_n = n;
 #pragma unroll
             for (int i = 0; i < 8; i++) st1[i] = st2[i] = 0.f;
         }
 
-        // ---- fragment ring, continuous across the steps of a unit: iteration `nx` of the step with phase PHN
-        auto frag_fetch = [&](auto phn, auto nxc, int ring) {
-            constexpr int PHN = decltype(phn)::value, nx = decltype(nxc)::value;
-            constexpr int tap = nx >> 1, ks = nx & 1;
-            constexpr int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-            aq[ring] = *reinterpret_cast<const bf16x8*>(wl + nx * 512);
+        // ---- fragment ring, continuous across the steps of a unit: group `g` = (kd, kw, ks) of the step with phase PHN
+        auto frag_fetch = [&](auto phn, auto gc, int ring) {
+            constexpr int PHN = decltype(phn)::value, g = decltype(gc)::value;
+            constexpr int kd = g / 6, kw = (g % 6) >> 1, ks = g & 1;
 #pragma unroll
-            for (int m = 0; m < 2; m++)
-                xq[ring][m] = *reinterpret_cast<const bf16x8*>(lds + ((PHN + kd) & 3) * PLANE + boff[m][kh][kw][ks]);
+            for (int r = 0; r < 4; r++)
+                xq[ring][r] = *reinterpret_cast<const bf16x8*>(bl + ((PHN + kd) & 3) * PLANE + (r * WW + kw) * PITCH + ks * 16);
         };
         // ---- epilogue pieces of a finished step (accumulators `ac`, output plane d0 + sp): accumulator layout
         // (lane = voxel, 4 couts per 8 bytes) -> wave-private LDS patch -> 16-byte stores that cover whole
         // 64-byte channel rows; bias before, residual after the transpose.  The pieces are issued between the
         // MFMAs of the NEXT step, so the matrix pipe does not idle while a plane is written out.
         auto epi_write = [&](const f32x16 (&ac)[2], int m, int q) {
-            float v[4];
+            f32x4 v;
 #pragma unroll
-            for (int i = 0; i < 4; i++) v[i] = ac[m][q * 4 + i] + bq[q][i];
-            store_vec<bf16, 4>(est + (m * 32 + (lane & 31)) * EST_PITCH + 8 * q + 4 * (lane >> 5), v);
+            for (int i = 0; i < 4; i++) v[i] = ac[m][q * 4 + i];
+            *reinterpret_cast<f32x4*>(est + (m * 32 + (lane & 31)) * EST_PITCH + 8 * q + 4 * (lane >> 5)) = v;
         };
         auto epi_vox = [&](int sp, int r) {
             const int row = (lane >> 2) + 16 * r;
             return (((int64_t)n * a.D + d0 + sp) * a.H + h0 + 2 * wave + (row >> 5)) * (int64_t)a.W + w0 + (row & 31);
         };
-        auto epi_row = [&](int sp, int r, const bf16x8& rres) {
-            const int row = (lane >> 2) + 16 * r, part = lane & 3;
+        // row phase in two halves one group apart: the LDS read is in flight while the other group's MFMAs run
+        auto epi_row_load = [&](int r, f32x4 (&rv)[2]) {
+            const float* src = est + ((lane >> 2) + 16 * r) * EST_PITCH + (lane & 3) * 8;
+            rv[0] = *reinterpret_cast<const f32x4*>(src);
+            rv[1] = *reinterpret_cast<const f32x4*>(src + 4);
+        };
+        auto epi_row_finish = [&](int sp, int r, const f32x4 (&rv)[2], const bf16x8& rres) {
+            const int part = lane & 3;
             float v[8];
-            load_vec<bf16, 8>(est + row * EST_PITCH + part * 8, v);
-            if (a.stat_slab) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = (float)(bf16)(rv[i >> 2][i & 3] + bias8[i]);   // the stored value
+            if constexpr (HAS_STATS) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     st1[i] += v[i];
                     st2[i] = fmaf(v[i], v[i], st2[i]);
                 }
             }
-            if (a.res) {
+            if constexpr (HAS_RES) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) v[i] += (float)rres[i];
             }
@@ -233,56 +268,69 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
         auto step = [&](auto phc, int s) {
             constexpr int PH = decltype(phc)::value;
             constexpr int PAR = PH & 1;
-            const bool pre = s + 3 <= a.DL + 1, has_prev = s > 0, last = s == a.DL - 1;
-            // long-latency loads first, in the order they are consumed: residual rows of the previous plane
-            // (used ~10 iterations in), then the input plane that is stored to LDS behind this step's barrier
+            const bool has_prev = s > 0, last = s == a.DL - 1;
+            // residual rows of the previous plane: used ~6 groups in (vmcnt retires in order; the only older loads
+            // are the plane loads of the previous step, two thirds of a step old by then)
+            f32x4 rv[2];
             bf16x8 rq[4];
-            if (has_prev && a.res) {
+            if constexpr (HAS_RES) {
+                if (has_prev) {
 #pragma unroll
-                for (int r = 0; r < 4; r++)
-                    rq[r] = *reinterpret_cast<const bf16x8*>(a.res + epi_vox(s - 1, r) * a.ldr + (lane & 3) * 8);
+                    for (int r = 0; r < 4; r++)
+                        rq[r] = *reinterpret_cast<const bf16x8*>(a.res + epi_vox(s - 1, r) * a.ldr + (lane & 3) * 8);
+                }
             }
-            bf16x8 stg[NSTG];
-            if (pre) load_plane(s + 3, stg);
-
-            static_for<0, 54>([&](auto itc) {
-                constexpr int it = decltype(itc)::value;
-#pragma unroll
-                for (int m = 0; m < 2; m++) {
-                    if (it == 0) {
-                        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        acc[PAR][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[it % XD], xq[it % XD][m], z, 0, 0, 0);
-                    } else {
-                        acc[PAR][m] =
-                            __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[it % XD], xq[it % XD][m], acc[PAR][m], 0, 0, 0);
-                    }
-                }
-                if (it == 36 - XD) {
-                    // taps with kd = 2 (iterations 36..53) read the plane that was stored behind the PREVIOUS step's
-                    // barrier; every wave is past iteration 17 of this step, so the slot of plane s-1 is free
+            SLIDE_STAMP(PH, 0, s)
+            static_for<0, NG>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                constexpr int kd = g / 6, kw = (g % 6) >> 1, ks = g & 1;
+                // output row m, tap row kh reads input row m + kh; the two accumulators alternate
+                static_for<0, 6>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    constexpr int m = j & 1, kh = j >> 1;
+                    constexpr int f = ((kd * 3 + kh) * 3 + kw) * 2 + ks;
+                    mfma_w<(f < WA_FRAGS), (g == 0 && kh == 0)>(acc[PAR][m], wreg[f], xq[g % XG][m + kh]);
+                });
+                if constexpr (g == 12 - (XG - 1)) {
+                    // the kd = 2 groups (12..17) read the plane that was stored behind the PREVIOUS step's barrier;
+                    // every wave is past the kd = 0 groups of this step, so the slot of plane s-1 is free
+                    SLIDE_STAMP(PH, 19, s)
                     __syncthreads();
-                    if (pre) store_plane((PH + 3) & 3, stg);
+                    SLIDE_STAMP(PH, 20, s)
+                    if (s + 3 <= a.DL + 1) store_plane(s + 3, (PH + 3) & 3, stg);
+                    SLIDE_STAMP(PH, 21, s)
                 }
-                if constexpr (it + XD < 54) {
-                    frag_fetch(std::integral_constant<int, PH>{}, std::integral_constant<int, (it + XD) % 54>{}, it % XD);
-                } else if (!last) {
-                    frag_fetch(std::integral_constant<int, (PH + 1) & 3>{}, std::integral_constant<int, (it + XD) % 54>{},
-                               it % XD);
+                if constexpr (g + XG - 1 < NG) {
+                    frag_fetch(std::integral_constant<int, PH>{}, std::integral_constant<int, g + XG - 1>{}, (g + XG - 1) % XG);
+                } else {
+                    if (!last)
+                        frag_fetch(std::integral_constant<int, (PH + 1) & 3>{},
+                                   std::integral_constant<int, g + XG - 1 - NG>{}, (g + XG - 1) % XG);
                 }
-                if constexpr (it >= 1 && it <= 8) {
-                    if (has_prev) epi_write(acc[PAR ^ 1], (it - 1) >> 2, (it - 1) & 3);
+                // epilogue of the previous plane, spread over the groups: 8 patch writes, then 4 rows (load | finish)
+                if constexpr (g <= 7) {
+                    if (has_prev) epi_write(acc[PAR ^ 1], g >> 2, g & 3);
                 }
-                if constexpr (it >= 10 && it <= 13) {
-                    if (has_prev) epi_row(s - 1, it - 10, rq[it - 10]);
+                if constexpr (g >= 8 && g <= 15 && (g & 1) == 0) {
+                    if (has_prev) epi_row_load((g - 8) >> 1, rv);
                 }
+                if constexpr (g >= 8 && g <= 15 && (g & 1) == 1) {
+                    if (has_prev) epi_row_finish(s - 1, (g - 8) >> 1, rv, rq[(g - 8) >> 1]);
+                }
+                if constexpr (g == 16) {
+                    // behind the last store of the step: vmcnt retires in order, and the next store's reuse of its
+                    // data registers waits for the previous store - it must not find these loads in front of it.
+                    // Stored to LDS behind the next step's barrier, two thirds of a step from now.
+                    if (s + 4 <= a.DL + 1) load_plane(s + 4, stg);
+                    SLIDE_STAMP(PH, 22, s)
+                }
+                SLIDE_STAMP(PH, g + 1, s)
                 __builtin_amdgcn_sched_barrier(0);
             });
         };
 
         // first fragments of step 0
-        static_for<0, XD>([&](auto itc) {
-            frag_fetch(std::integral_constant<int, 0>{}, itc, decltype(itc)::value);
-        });
+        static_for<0, XG - 1>([&](auto gc) { frag_fetch(std::integral_constant<int, 0>{}, gc, decltype(gc)::value); });
         for (int s4 = 0; s4 < a.DL; s4 += 4) {
             step(std::integral_constant<int, 0>{}, s4);
             step(std::integral_constant<int, 1>{}, s4 + 1);
@@ -295,17 +343,30 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-                rq[r] = a.res ? *reinterpret_cast<const bf16x8*>(a.res + epi_vox(a.DL - 1, r) * a.ldr + (lane & 3) * 8) : z8;
+                rq[r] = HAS_RES ? *reinterpret_cast<const bf16x8*>(a.res + epi_vox(a.DL - 1, r) * a.ldr + (lane & 3) * 8) : z8;
             }
 #pragma unroll
             for (int j = 0; j < 8; j++) epi_write(acc[1], j >> 2, j & 3);
 #pragma unroll
-            for (int r = 0; r < 4; r++) epi_row(a.DL - 1, r, rq[r]);
+            for (int r = 0; r < 4; r++) {
+                f32x4 rv[2];
+                epi_row_load(r, rv);
+                epi_row_finish(a.DL - 1, r, rv, rq[r]);
+            }
         }
     }
     stat_flush();
+#ifdef RU3D_SLIDE_STAMPS
+    __syncthreads();
+    if (blockIdx.x == 0 && tid < 96 && a.stamps) a.stamps[tid] = stamp_s[tid];
+#endif
 }
 }  // namespace
+
+#ifdef RU3D_SLIDE_STAMPS
+static long long* g_slide_stamps = nullptr;
+extern "C" void ru3d_debug_slide_stamps(long long* dev_buf) { g_slide_stamps = dev_buf; }
+#endif
 
 // Work decomposition: units = N x dsplit x (H/8) x (W/32) columns of DL = D/dsplit planes (+2 halo planes each).
 // dsplit is the divisor of D (DL a multiple of 4) with the shortest makespan on 256 CUs.
@@ -360,6 +421,12 @@ int conv_slide_launch(const void* x, const void* w, const float* bias, const voi
     a.ldx = g.ldx; a.ldy = g.ldy; a.ldr = g.ldr;
     a.flip = g.flip;
     a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w; a.dsplit = p.dsplit; a.DL = p.DL; a.units = p.units;
-    hipLaunchKernelGGL(conv3_s1_slide32_kernel, dim3(p.grid), dim3(256), 0, st, a);
+#ifdef RU3D_SLIDE_STAMPS
+    a.stamps = g_slide_stamps;
+#endif
+    if (res && stat_slab) hipLaunchKernelGGL((conv3_s1_slide32_kernel<true, true>), dim3(p.grid), dim3(256), 0, st, a);
+    else if (res) hipLaunchKernelGGL((conv3_s1_slide32_kernel<true, false>), dim3(p.grid), dim3(256), 0, st, a);
+    else if (stat_slab) hipLaunchKernelGGL((conv3_s1_slide32_kernel<false, true>), dim3(p.grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3_s1_slide32_kernel<false, false>), dim3(p.grid), dim3(256), 0, st, a);
     return ru3d_check_launch("conv3_s1_slide32");
 }

@@ -4,14 +4,15 @@ of the bytes of a 16-B/lane streaming read; WRITE_SIZE is exact; both are in KiB
     python tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
 import collections, csv, glob, json, sys
 
-def mean_counter(d, counter, kernel_sub):
+def mean_counter(d, counter, kernel_subs):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if r["Counter_Name"] == counter and kernel_sub in r["Kernel_Name"]]
+            if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in kernel_subs)]
     return sum(vals) / len(vals), len(vals)
 
 out = {}
-for name, sub in (("conv3d k3 s1 32->32 on 2x128^3", "conv3_s1_mfma_kernel"), ("wgrad 32->32 on 2x128^3", "wgrad3_s1_mfma_kernel")):
+for name, sub in (("conv3d k3 s1 32->32 on 2x128^3", ("conv3_s1_slide32_kernel", "conv3_s1_pc_kernel", "conv3_s1_mfma_kernel")),
+                  ("wgrad 32->32 on 2x128^3", ("wgrad3_s1_mfma_kernel",))):
     fetch, n1 = mean_counter(sys.argv[1], "FETCH_SIZE", sub)
     write, n2 = mean_counter(sys.argv[2], "WRITE_SIZE", sub)
     out[name] = {"fetch_size_kib_raw": fetch, "write_size_kib": write, "launches": [n1, n2],
