@@ -68,7 +68,7 @@ int wgrad_mfma_launch(const void* x, const void* dy, float* dw, void* ws, size_t
 
 // conv_slide.hip (3x3x3 stride-1, 32 -> 32 channels: D-sliding plane ring, weights resident in LDS)
 struct SlidePlan {
-    int dsplit, DL, tiles_h, tiles_w, units, grid;
+    int dsplit, DL, tiles_h, tiles_w, units, grid, ny;
 };
 bool slide_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* out);
 int conv_slide_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,

@@ -602,7 +602,7 @@ static void stats_slab_geom(const ConvGeom& g, int* gx, int* gy, int* cb) {
     SlidePlan sp;
     if (slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) {
         *gx = sp.grid;
-        *gy = 1;
+        *gy = sp.ny;
         *cb = 32;
         return;
     }

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
         constexpr int f = decltype(fc)::value;
         constexpr int tap = f >> 1, ks = f & 1;
         const int st = a.flip ? 26 - tap : tap;
-        wreg[f] = a.w[(st * 2 + ks) * 64 + lane];
+        wreg[f] = a.w[((st * 2 + ks) * gridDim.y + blockIdx.y) * 64 + lane];
     });
 
     // ---- staging constants: this thread's pieces of the wave's 85 plane rows
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
     int cur_n = -1;
     auto stat_flush = [&]() {
         if (!HAS_STATS || cur_n < 0) return;
-        float* dst = a.stat_slab + ((((int64_t)blockIdx.x * 4 + wave) * a.N + cur_n) * 32) * 2;
+        float* dst = a.stat_slab + ((((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * a.N + cur_n) * 32) * 2;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             float s1 = st1[i], s2 = st2[i];
@@ -154,7 +154,10 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
     // bias of the 8 channels this lane stores in the row phase of the epilogue
     float bias8[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) bias8[i] = a.bias ? a.bias[(lane & 3) * 8 + i] : 0.f;
+    for (int i = 0; i < 8; i++) bias8[i] = a.bias ? a.bias[blockIdx.y * 32 + (lane & 3) * 8 + i] : 0.f;
+    // output channels [32 * blockIdx.y, +32): Cout = 64 runs as two independent 32-channel slices of the grid
+    bf16* const ybase = a.y + blockIdx.y * 32;
+    const bf16* const rbase = a.res + blockIdx.y * 32;
 
     const int G = gridDim.x;
     const bool remap = (a.units % 8) == 0 && (G % 8) == 0;
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) v[i] += (float)rres[i];
             }
-            store_vec<bf16, 8>(a.y + epi_vox(sp, r) * a.ldy + part * 8, v);
+            store_vec<bf16, 8>(ybase + epi_vox(sp, r) * a.ldy + part * 8, v);
         };
 
         auto step = [&](auto phc, int s) {
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
                 if (has_prev) {
 #pragma unroll
                     for (int r = 0; r < 4; r++)
-                        rq[r] = *reinterpret_cast<const bf16x8*>(a.res + epi_vox(s - 1, r) * a.ldr + (lane & 3) * 8);
+                        rq[r] = *reinterpret_cast<const bf16x8*>(rbase + epi_vox(s - 1, r) * a.ldr + (lane & 3) * 8);
                 }
             }
             SLIDE_STAMP(PH, 0, s)
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-                rq[r] = HAS_RES ? *reinterpret_cast<const bf16x8*>(a.res + epi_vox(a.DL - 1, r) * a.ldr + (lane & 3) * 8) : z8;
+                rq[r] = HAS_RES ? *reinterpret_cast<const bf16x8*>(rbase + epi_vox(a.DL - 1, r) * a.ldr + (lane & 3) * 8) : z8;
             }
 #pragma unroll
             for (int j = 0; j < 8; j++) epi_write(acc[1], j >> 2, j & 3);
@@ -368,11 +371,13 @@ static long long* g_slide_stamps = nullptr;
 extern "C" void ru3d_debug_slide_stamps(long long* dev_buf) { g_slide_stamps = dev_buf; }
 #endif
 
-// Work decomposition: units = N x dsplit x (H/8) x (W/32) columns of DL = D/dsplit planes (+2 halo planes each).
-// dsplit is the divisor of D (DL a multiple of 4) with the shortest makespan on 256 CUs.
+// Work decomposition: units = N x dsplit x (H/8) x (W/32) columns of DL = D/dsplit planes (+2 halo planes each),
+// times Cout/32 output-channel slices (grid.y).  dsplit is the divisor of D (DL a multiple of 4) with the shortest
+// makespan on 256 CUs.
 bool slide_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* out) {
     static const int mode = getenv("RU3D_CONV_SLIDE") ? atoi(getenv("RU3D_CONV_SLIDE")) : 1;
-    if (mode == 0 || Cin != 32 || Cout != 32 || (H % TH) || (W % TW) || D < 4) return false;
+    if (mode == 0 || Cin != 32 || (Cout != 32 && Cout != 64) || (H % TH) || (W % TW) || D < 4) return false;
+    const int ny = Cout / 32;
     const int64_t cols = (int64_t)N * (H / TH) * (W / TW);
     int64_t best_cost = -1;
     int best = 0;
@@ -381,8 +386,11 @@ bool slide_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* o
         const int dl = D / ds;
         if (dl % 4) continue;
         const int64_t units = cols * ds;
-        if (units > 0x7fffffff) break;
-        const int64_t cost = ((units + 255) / 256) * (dl + 3);
+        if (units * ny > 0x7fffffff) break;
+        // grid.x = min(units, 256 / ny rounded to 8) persistent workgroups per slice
+        int64_t gx = 256 / ny;
+        if (gx > units) gx = units;
+        const int64_t cost = ((units + gx - 1) / gx) * (dl + 3);
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
             best = ds;
@@ -391,16 +399,17 @@ bool slide_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* o
     if (!best) return false;
     const int64_t units = cols * best;
     // worth it only when the 256 CUs are reasonably filled
-    const double ideal = (double)cols * D / 256.0;
-    if (units < 128 || (double)best_cost > 1.6 * ideal + 8) return false;
+    const double ideal = (double)cols * ny * D / 256.0;
+    if (units * ny < 128 || (double)best_cost > 1.6 * ideal + 8) return false;
     out->dsplit = best;
     out->DL = D / best;
     out->tiles_h = H / TH;
     out->tiles_w = W / TW;
     out->units = (int)units;
-    int g = units < 256 ? (int)units : 256;
+    int g = units < 256 / ny ? (int)units : 256 / ny;
     if ((units % 8) == 0 && g >= 8) g = (g / 8) * 8;
     out->grid = g;
+    out->ny = ny;
     return true;
 }
 
@@ -424,9 +433,9 @@ int conv_slide_launch(const void* x, const void* w, const float* bias, const voi
 #ifdef RU3D_SLIDE_STAMPS
     a.stamps = g_slide_stamps;
 #endif
-    if (res && stat_slab) hipLaunchKernelGGL((conv3_s1_slide32_kernel<true, true>), dim3(p.grid), dim3(256), 0, st, a);
-    else if (res) hipLaunchKernelGGL((conv3_s1_slide32_kernel<true, false>), dim3(p.grid), dim3(256), 0, st, a);
-    else if (stat_slab) hipLaunchKernelGGL((conv3_s1_slide32_kernel<false, true>), dim3(p.grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv3_s1_slide32_kernel<false, false>), dim3(p.grid), dim3(256), 0, st, a);
+    if (res && stat_slab) hipLaunchKernelGGL((conv3_s1_slide32_kernel<true, true>), dim3(p.grid, p.ny), dim3(256), 0, st, a);
+    else if (res) hipLaunchKernelGGL((conv3_s1_slide32_kernel<true, false>), dim3(p.grid, p.ny), dim3(256), 0, st, a);
+    else if (stat_slab) hipLaunchKernelGGL((conv3_s1_slide32_kernel<false, true>), dim3(p.grid, p.ny), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv3_s1_slide32_kernel<false, false>), dim3(p.grid, p.ny), dim3(256), 0, st, a);
     return ru3d_check_launch("conv3_s1_slide32");
 }
