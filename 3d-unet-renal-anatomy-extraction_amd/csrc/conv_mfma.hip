@@ -813,6 +813,182 @@ __global__ __launch_bounds__(256) void conv_direct_mfma_kernel(DirectArgs a) {
     }
 }
 
+// The same forms on the deep levels (8^3 .. 16^3 voxels, hundreds of channels): one 256-voxel workgroup per 64 couts
+// leaves tens of workgroups, each walking thousands of dependent (load, MFMA) pairs.  Here a workgroup owns ONE
+// 32-voxel column tile (transposed form: 32 half-resolution positions of one parity class, blockIdx.z) x NT cout
+// tiles, its 4 waves split the (tap, k-step) iterations, every wave keeps the next iteration's fragments in flight,
+// and the four partial tiles are summed through LDS in a fixed order before the fused bias / residual / store.
+template <int NT, bool TRANSPOSED>
+__global__ __launch_bounds__(256) void conv_direct_ksplit_kernel(DirectArgs a) {
+    __shared__ float red[4][NT][64][17];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NTT = a.Cout / 32, KS = a.Cin / 16;
+    const int co_blk = blockIdx.y * (NT * 32);
+    const int taps = a.k * a.k * a.k;
+    const int cl = TRANSPOSED ? (int)blockIdx.z : 0;
+
+    // this lane's output voxel (column of the MFMA tile)
+    int n_, od, oh, ow, ba = 0, bb = 0, bc = 0;
+    bool valid;
+    {
+        const int64_t v = (int64_t)blockIdx.x * 32 + (lane & 31);
+        const bool ok = v < a.total;
+        const int64_t vv = ok ? v : 0;
+        if (!TRANSPOSED) {
+            ow = (int)(vv % a.Wo);
+            int64_t t = vv / a.Wo;
+            oh = (int)(t % a.Ho);
+            t /= a.Ho;
+            od = (int)(t % a.Do);
+            n_ = (int)(t / a.Do);
+            valid = ok;
+        } else {
+            bc = (int)(vv % a.hw);
+            int64_t t = vv / a.hw;
+            bb = (int)(t % a.hh);
+            t /= a.hh;
+            ba = (int)(t % a.hd);
+            n_ = (int)(t / a.hd);
+            od = 2 * ba + (cl >> 2);
+            oh = 2 * bb + ((cl >> 1) & 1);
+            ow = 2 * bc + (cl & 1);
+            valid = ok && od < a.Do && oh < a.Ho && ow < a.Wo;
+        }
+    }
+    // taps that feed this tile, per axis: gather form all k; transposed form those with (class bit + pad - k) even
+    int nkd, nkh, nkw, k0d, k0h, k0w, kstep;
+    if (!TRANSPOSED) {
+        nkd = nkh = nkw = a.k;
+        k0d = k0h = k0w = 0;
+        kstep = 1;
+    } else {
+        auto axis = [&](int bit, int& nk, int& k0) {
+            k0 = (bit + a.pad) & 1;                 // first k with the right parity
+            nk = k0 < a.k ? (a.k - k0 + 1) / 2 : 0;
+        };
+        axis(cl >> 2, nkd, k0d);
+        axis((cl >> 1) & 1, nkh, k0h);
+        axis(cl & 1, nkw, k0w);
+        kstep = 2;
+    }
+    const int T = nkd * nkh * nkw * KS;                       // iterations of this tile
+    const int j_lo = (T * wave) / 4, j_hi = (T * (wave + 1)) / 4;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
+
+    auto fetch = [&](int j, bf16x8& xb, bf16x8 (&wa)[NT]) {
+        const int ks = j % KS;
+        int tq = j / KS;
+        const int kw = k0w + kstep * (tq % nkw);
+        tq /= nkw;
+        const int kh = k0h + kstep * (tq % nkh);
+        const int kd = k0d + kstep * (tq / nkh);
+        int id, ih, iw;
+        if (TRANSPOSED) {
+            id = ba + (((cl >> 2) + a.pad - kd) >> 1);
+            ih = bb + ((((cl >> 1) & 1) + a.pad - kh) >> 1);
+            iw = bc + (((cl & 1) + a.pad - kw) >> 1);
+        } else {
+            id = od * a.stride + kd - a.pad;
+            ih = oh * a.stride + kh - a.pad;
+            iw = ow * a.stride + kw - a.pad;
+        }
+        const int tap = (kd * a.k + kh) * a.k + kw;
+        const int wtap = a.flip ? taps - 1 - tap : tap;
+        const bool inb = valid && id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+        const bf16* xp = a.x + ((((int64_t)n_ * a.Di + (inb ? id : 0)) * a.Hi + (inb ? ih : 0)) * a.Wi + (inb ? iw : 0)) * a.ldx +
+                         (lane >> 5) * 8 + ks * 16;
+        const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xp);   // always a valid address; zeroed below
+        xb = inb ? xv : z8;
+        const bf16x8* wrow = a.w + (((int64_t)wtap * KS + ks) * NTT + blockIdx.y * NT) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NT; t++) wa[t] = wrow[t * 64];
+    };
+
+    if (j_lo < j_hi) {
+        bf16x8 xb0, xb1, wa0[NT], wa1[NT];
+        fetch(j_lo, xb0, wa0);
+        int j = j_lo;
+        for (; j + 1 < j_hi; j += 2) {
+            fetch(j + 1, xb1, wa1);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa0[t], xb0, acc[t], 0, 0, 0);
+            if (j + 2 < j_hi) fetch(j + 2, xb0, wa0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[t], xb1, acc[t], 0, 0, 0);
+        }
+        if (j < j_hi) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa0[t], xb0, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) red[wave][t][lane][i] = acc[t][i];
+    __syncthreads();
+
+    // thread -> (voxel, 8 consecutive couts); D layout: col = lane & 31 (voxel), row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+    const int vox_l = tid >> 3, cg = tid & 7;
+    if (cg * 8 >= NT * 32) return;
+    // re-derive the voxel of column vox_l (it is lane vox_l's voxel)
+    const int64_t v2 = (int64_t)blockIdx.x * 32 + vox_l;
+    if (v2 >= a.total) return;
+    int n2, d2, h2, w2;
+    if (!TRANSPOSED) {
+        w2 = (int)(v2 % a.Wo);
+        int64_t t = v2 / a.Wo;
+        h2 = (int)(t % a.Ho);
+        t /= a.Ho;
+        d2 = (int)(t % a.Do);
+        n2 = (int)(t / a.Do);
+    } else {
+        const int c2 = (int)(v2 % a.hw);
+        int64_t t = v2 / a.hw;
+        const int b2 = (int)(t % a.hh);
+        t /= a.hh;
+        const int a2 = (int)(t % a.hd);
+        n2 = (int)(t / a.hd);
+        d2 = 2 * a2 + (cl >> 2);
+        h2 = 2 * b2 + ((cl >> 1) & 1);
+        w2 = 2 * c2 + (cl & 1);
+        if (d2 >= a.Do || h2 >= a.Ho || w2 >= a.Wo) return;
+    }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int co = cg * 8 + e;
+        const int t = co >> 5, r = co & 31;
+        const int h = (r >> 2) & 1, i = (r & 3) + 4 * (r >> 3);
+        const int ln = vox_l + 32 * h;
+        v[e] = (red[0][t][ln][i] + red[1][t][ln][i]) + (red[2][t][ln][i] + red[3][t][ln][i]);
+    }
+    const int c0 = co_blk + cg * 8;
+    if (a.bias) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] += a.bias[c0 + e];
+    }
+    if (a.zero_far && (d2 == a.Do - 1 || h2 == a.Ho - 1 || w2 == a.Wo - 1)) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = 0.f;
+    }
+    const int64_t vox = (((int64_t)n2 * a.Do + d2) * a.Ho + h2) * a.Wo + w2;
+    if (a.res) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] += (float)a.res[vox * a.ldr + c0 + e];
+    }
+    // y pitch and base are 8-byte aligned (checked by the launcher); two 4-element stores
+    float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
+    store_vec<bf16, 4>(a.y + vox * a.ldy + c0, lo);
+    store_vec<bf16, 4>(a.y + vox * a.ldy + c0 + 4, hi);
+}
+
 static int launch_direct(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
                          hipStream_t st) {
     DirectArgs a;
@@ -836,6 +1012,20 @@ static int launch_direct(const void* x, const void* w, const float* bias, const 
         nblk = (a.total + 255) / 256;
     }
     if (nblk > 0x7fffffff) return ru3d_fail(-1, "conv_direct_mfma: grid too large");
+    static const int ksplit_mode = getenv("RU3D_CONV_KSPLIT") ? atoi(getenv("RU3D_CONV_KSPLIT")) : 1;
+    if (ksplit_mode && nblk * (g.Cout / (nt2 ? 64 : 32)) < 384) {
+        // few, long workgroups: split the reduction over the waves of 32-voxel workgroups instead
+        const int64_t tiles = (a.total + 31) / 32;
+        dim3 gk((unsigned)tiles, g.Cout / (nt2 ? 64 : 32), g.transposed ? 8 : 1);
+        if (g.transposed) {
+            if (nt2) hipLaunchKernelGGL((conv_direct_ksplit_kernel<2, true>), gk, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_direct_ksplit_kernel<1, true>), gk, dim3(256), 0, st, a);
+        } else {
+            if (nt2) hipLaunchKernelGGL((conv_direct_ksplit_kernel<2, false>), gk, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_direct_ksplit_kernel<1, false>), gk, dim3(256), 0, st, a);
+        }
+        return ru3d_check_launch("conv_direct_ksplit");
+    }
     dim3 grid((unsigned)nblk, g.Cout / (nt2 ? 64 : 32));
     if (g.transposed) {
         if (nt2) hipLaunchKernelGGL((conv_direct_mfma_kernel<2, true>), grid, dim3(256), 0, st, a);
