@@ -989,6 +989,170 @@ __global__ __launch_bounds__(256) void conv_direct_ksplit_kernel(DirectArgs a) {
     store_vec<bf16, 4>(a.y + vox * a.ldy + c0 + 4, hi);
 }
 
+// Transposed form (ConvTranspose3d k3 s2 p1 forward, stride-2 conv input gradient) on the large levels through an
+// LDS tile: a workgroup owns 128 half-resolution positions (TD x TH x TW) and stages their (TD+1)(TH+1)(TW+1) input
+// rows ONCE - all 8 output parity classes read the same 2x2x2 neighbourhoods, so the 27 taps cost one global read
+// of the input instead of 27 L1/L2 gathers.  Waves take whole parity classes (8 | 4+2+1 | 4+2 | 4+2 taps); per class
+// a wave holds the 4 column tiles of the workgroup, so every weight fragment (global, prefetched one iteration
+// ahead) feeds 4 MFMAs per cout tile.  Row pitch Cin*2 + 16 bytes: conflict-free ds_read_b128 over a W-run.
+template <int NT, int TD, int TH, int TW>
+__global__ __launch_bounds__(256, 2) void convt_tile_mfma_kernel(DirectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) bf16 tile_lds[];
+    static_assert(TD * TH * TW == 128, "128 half-resolution positions per workgroup");
+    constexpr int HD = TD + 1, HH = TH + 1, HW = TW + 1, ROWS = HD * HH * HW;
+    constexpr int MT = 4;                       // column tiles of 32 positions
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NTT = a.Cout / 32, KS = a.Cin / 16;
+    const int pitch = a.Cin + 8;                 // bf16 elements
+    const int co_blk = blockIdx.y * (NT * 32);
+
+    // tile origin in half-resolution coordinates
+    const int tw_n = (a.hw + TW - 1) / TW, th_n = (a.hh + TH - 1) / TH, td_n = (a.hd + TD - 1) / TD;
+    int t = blockIdx.x;
+    const int c0 = (t % tw_n) * TW;
+    t /= tw_n;
+    const int b0 = (t % th_n) * TH;
+    t /= th_n;
+    const int a0 = (t % td_n) * TD;
+    const int n = t / td_n;
+
+    // ---- stage the input rows (zero outside the tensor)
+    const int ppr = a.Cin / 8;                   // 16-byte pieces per row
+    for (int p = tid; p < ROWS * ppr; p += 256) {
+        const int r = p / ppr, piece = p - r * ppr;
+        const int zc = r % HW, zb = (r / HW) % HH, za = r / (HW * HH);
+        const int ia = a0 + za, ib = b0 + zb, ic = c0 + zc;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ia < a.Di && ib < a.Hi && ic < a.Wi)
+            v = *reinterpret_cast<const bf16x8*>(a.x + ((((int64_t)n * a.Di + ia) * a.Hi + ib) * a.Wi + ic) * a.ldx + piece * 8);
+        *reinterpret_cast<bf16x8*>(tile_lds + r * pitch + piece * 8) = v;
+    }
+    __syncthreads();
+
+    // column tile m of the workgroup: positions f = m*32 + (lane & 31)
+    int rowm[MT], pa[MT], pb[MT], pc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        const int f = m * 32 + (lane & 31);
+        pc[m] = f % TW;
+        pb[m] = (f / TW) % TH;
+        pa[m] = f / (TW * TH);
+        rowm[m] = ((pa[m] * HH + pb[m]) * HW + pc[m]) * pitch + (lane >> 5) * 8;
+    }
+
+    // classes of this wave, heaviest first: {7} | {3, 1, 0} | {5, 2} | {6, 4}   (taps 8 | 4+2+1 | 4+2 | 4+2)
+    const int ncls = wave == 0 ? 1 : (wave == 1 ? 3 : 2);
+    for (int ci = 0; ci < ncls; ci++) {
+        const int cl = wave == 0 ? 7 : wave == 1 ? (ci == 0 ? 3 : (ci == 1 ? 1 : 0)) : wave == 2 ? (ci == 0 ? 5 : 2) : (ci == 0 ? 6 : 4);
+        const int bd = cl >> 2, bh = (cl >> 1) & 1, bw = cl & 1;
+        // taps of the class per axis: bit 0 -> k = 1 (input offset 0); bit 1 -> k = 0 (offset 1), k = 2 (offset 0)
+        const int nkd = 1 + bd, nkh = 1 + bh, nkw = 1 + bw;
+        const int T = nkd * nkh * nkw * KS;
+
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int tt = 0; tt < NT; tt++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[m][tt][i] = 0.f;
+
+        auto wfetch = [&](int j, bf16x8 (&wa)[NT], int& roff) {
+            const int ks = j % KS;
+            int tq = j / KS;
+            const int iw = tq % nkw;
+            tq /= nkw;
+            const int ih = tq % nkh;
+            const int idd = tq / nkh;
+            // axis with class bit 1: index 0 -> k = 0 (offset 1), index 1 -> k = 2 (offset 0); bit 0: k = 1 (offset 0)
+            const int kd = bd ? 2 * idd : 1, kh = bh ? 2 * ih : 1, kw = bw ? 2 * iw : 1;
+            const int dd = bd ? 1 - idd : 0, dh = bh ? 1 - ih : 0, dw = bw ? 1 - iw : 0;
+            const int tap = (kd * 3 + kh) * 3 + kw;
+            const int wtap = a.flip ? 26 - tap : tap;
+            const bf16x8* wrow = a.w + (((int64_t)wtap * KS + ks) * NTT + blockIdx.y * NT) * 64 + lane;
+#pragma unroll
+            for (int tt = 0; tt < NT; tt++) wa[tt] = wrow[tt * 64];
+            roff = ((dd * HH + dh) * HW + dw) * pitch + ks * 16;
+        };
+        auto compute = [&](const bf16x8 (&wa)[NT], int roff) {
+            bf16x8 xb[MT];
+#pragma unroll
+            for (int m = 0; m < MT; m++) xb[m] = *reinterpret_cast<const bf16x8*>(tile_lds + rowm[m] + roff);
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int tt = 0; tt < NT; tt++)
+                    acc[m][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[tt], xb[m], acc[m][tt], 0, 0, 0);
+        };
+        {
+            bf16x8 w0[NT], w1[NT];
+            int r0, r1;
+            wfetch(0, w0, r0);
+            int j = 0;
+            for (; j + 1 < T; j += 2) {
+                wfetch(j + 1, w1, r1);
+                compute(w0, r0);
+                if (j + 2 < T) wfetch(j + 2, w0, r0);
+                compute(w1, r1);
+            }
+            if (j < T) compute(w0, r0);
+        }
+
+        // ---- epilogue of the class: output voxel (2a + bd, 2b + bh, 2c + bw)
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            const int od = 2 * (a0 + pa[m]) + bd, oh = 2 * (b0 + pb[m]) + bh, ow = 2 * (c0 + pc[m]) + bw;
+            if (od >= a.Do || oh >= a.Ho || ow >= a.Wo) continue;
+            const int64_t vox = (((int64_t)n * a.Do + od) * a.Ho + oh) * a.Wo + ow;
+            const bool far = a.zero_far && (od == a.Do - 1 || oh == a.Ho - 1 || ow == a.Wo - 1);
+#pragma unroll
+            for (int tt = 0; tt < NT; tt++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int cc = co_blk + tt * 32 + 8 * q + 4 * (lane >> 5);
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = acc[m][tt][q * 4 + i];
+                    if (a.bias) {
+                        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + cc);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) v[i] += b[i];
+                    }
+                    if (far) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) v[i] = 0.f;
+                    }
+                    if (a.res) {
+                        float r[4];
+                        load_vec<bf16, 4>(a.res + vox * a.ldr + cc, r);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) v[i] += r[i];
+                    }
+                    store_vec<bf16, 4>(a.y + vox * a.ldy + cc, v);
+                }
+            }
+        }
+    }
+}
+
+template <int NT, int TD, int TH, int TW>
+static int launch_convt_tile(const DirectArgs& a, int N, hipStream_t st) {
+    const int tw_n = (a.hw + TW - 1) / TW, th_n = (a.hh + TH - 1) / TH, td_n = (a.hd + TD - 1) / TD;
+    const int64_t nblk = (int64_t)N * td_n * th_n * tw_n;
+    if (nblk > 0x7fffffff) return ru3d_fail(-1, "convt_tile: grid too large");
+    const size_t lds = (size_t)(TD + 1) * (TH + 1) * (TW + 1) * (a.Cin + 8) * sizeof(bf16);
+    auto kern = convt_tile_mfma_kernel<NT, TD, TH, TW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return ru3d_fail(-1, "convt_tile: cannot raise the dynamic LDS limit");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk, a.Cout / (NT * 32)), dim3(256), lds, st, a);
+    return ru3d_check_launch("convt_tile_mfma");
+}
+
 static int launch_direct(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
                          hipStream_t st) {
     DirectArgs a;
@@ -1025,6 +1189,16 @@ static int launch_direct(const void* x, const void* w, const float* bias, const 
             else hipLaunchKernelGGL((conv_direct_ksplit_kernel<1, false>), gk, dim3(256), 0, st, a);
         }
         return ru3d_check_launch("conv_direct_ksplit");
+    }
+    static const int tile_mode = getenv("RU3D_CONVT_TILE") ? atoi(getenv("RU3D_CONVT_TILE")) : 1;
+    if (tile_mode && g.transposed && g.k == 3 && g.pad == 1) {
+        // (TD+1)(TH+1)(TW+1) rows of Cin*2+16 bytes must fit in LDS: Cin <= 256 with the 16-wide tile, 128 with the 32-wide
+        if (a.hw >= 24 && g.Cin <= 128) {
+            return nt2 ? launch_convt_tile<2, 2, 2, 32>(a, g.N, st) : launch_convt_tile<1, 2, 2, 32>(a, g.N, st);
+        }
+        if (a.hw >= 12 && g.Cin <= 256) {
+            return nt2 ? launch_convt_tile<2, 2, 4, 16>(a, g.N, st) : launch_convt_tile<1, 2, 4, 16>(a, g.N, st);
+        }
     }
     dim3 grid((unsigned)nblk, g.Cout / (nt2 ? 64 : 32));
     if (g.transposed) {
