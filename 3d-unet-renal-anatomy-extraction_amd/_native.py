@@ -56,7 +56,7 @@ SIGNATURES = {
     "ru3d_reduce_workspace_bytes": (_sz, [_P]),
     "ru3d_instnorm_stats": (_i, [_P, _vp, _vp, _vp, _vp, _sz, _f, _i, _vp]),
     "ru3d_in_lrelu_fwd": (_i, [_P, _vp, _vp, _P, _P, _f, _i, _vp]),
-    "ru3d_in_lrelu_bwd": (_i, [_P, _P, _P, _vp, _vp, _P, _P, _vp, _sz, _f, _i, _i, _vp]),
+    "ru3d_in_lrelu_bwd": (_i, [_P, _P, _P, _vp, _vp, _P, _P, _vp, _sz, _f, _i, _vp, _i, _vp]),
     "ru3d_channel_sum": (_i, [_P, _vp, _vp, _sz, _i, _vp]),
     "ru3d_dropout3d_scale": (_i, [_vp, _i, _f, _u64, _u64, _vp]),
     "ru3d_copy_channels": (_i, [_P, _P, _i, _vp]),
@@ -156,19 +156,31 @@ def to_ndhwc(t):
     return t.contiguous(memory_format=torch.channels_last_3d)
 
 
+_GEOM = {}
+
+
 def desc(t):
-    """ru3d_tensor descriptor of an NDHWC-strided [N,C,D,H,W] torch tensor."""
-    require_device(t)
-    if not is_ndhwc(t):
-        raise Ru3dError("ru3d: tensor of shape %s / strides %s is not NDHWC" % (tuple(t.shape), t.stride()))
-    n, c, d, h, w = t.shape
-    ld = c
-    for size, stride, inner in ((w, t.stride(4), 1), (h, t.stride(3), w), (d, t.stride(2), h * w),
-                                (n, t.stride(0), d * h * w)):
-        if size > 1:
-            ld = stride // inner
-            break
-    return Tensor(t.data_ptr(), n, d, h, w, c, ld)
+    """ru3d_tensor descriptor of an NDHWC-strided [N,C,D,H,W] torch tensor.  The (shape, strides) -> geometry
+    part is memoised: the same few dozen layouts recur every step."""
+    if not t.is_cuda:
+        require_device(t)
+    key = (t.shape, t.stride())
+    g = _GEOM.get(key)
+    if g is None:
+        if not is_ndhwc(t):
+            raise Ru3dError("ru3d: tensor of shape %s / strides %s is not NDHWC" % (tuple(t.shape), t.stride()))
+        n, c, d, h, w = t.shape
+        ld = c
+        for size, stride, inner in ((w, t.stride(4), 1), (h, t.stride(3), w), (d, t.stride(2), h * w),
+                                    (n, t.stride(0), d * h * w)):
+            if size > 1:
+                ld = stride // inner
+                break
+        g = (n, d, h, w, c, ld)
+        if len(_GEOM) > 4096:
+            _GEOM.clear()
+        _GEOM[key] = g
+    return Tensor(t.data_ptr(), *g)
 
 
 def ref(d):

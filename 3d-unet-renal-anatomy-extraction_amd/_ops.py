@@ -38,37 +38,56 @@ def pack_weight(w, role, dtype, stride=1):
     return out
 
 
+_PACK_PLANS = {}
+
+
 def pack_weights(specs, dtype):
     """specs: list of (weight, role, stride) -> list of packed tensors, produced by ONE kernel launch per
-    RU3D_PACK_MAX weights (the packs share one allocation)."""
+    RU3D_PACK_MAX weights (the packs share one allocation).  The size/offset plan and the ctypes item arrays of a
+    spec list are built once and reused while the parameters stay where they are (same data pointers)."""
     code = N.dtype_code(dtype)
-    metas, sizes = [], []
-    for w, role, stride in specs:
-        N.require_device(w, "weight")
-        w = w.detach()
-        if w.dtype != torch.float32 or not w.is_contiguous():
-            w = w.float().contiguous()
-        k = w.shape[2]
-        if role in (N.ROLE_CONVT_FWD, N.ROLE_CONVT_DGRAD):
-            cin, cout, stride = w.shape[0], w.shape[1], 2
-        else:
-            cout, cin = w.shape[0], w.shape[1]
-        nbytes = N.lib.ru3d_packed_weight_bytes(cout, cin, k, stride, role, code)
-        if nbytes == 0:
-            raise N.Ru3dError("ru3d: cannot pack weight of shape %s" % (tuple(w.shape),))
-        metas.append((w, cout, cin, k, stride, role))
-        sizes.append((nbytes + 255) // 256 * 256)
-    buf = torch.empty(sum(sizes), dtype=torch.uint8, device=specs[0][0].device)
-    outs, off = [], 0
-    for sz in sizes:
-        outs.append(buf[off:off + sz])
-        off += sz
-    for i0 in range(0, len(metas), N.PACK_MAX):
-        chunk = metas[i0:i0 + N.PACK_MAX]
-        items = (N.PackItem * len(chunk))()
-        for j, (w, cout, cin, k, stride, role) in enumerate(chunk):
-            items[j] = N.PackItem(w.data_ptr(), outs[i0 + j].data_ptr(), cout, cin, k, stride, role)
-        check(N.lib.ru3d_pack_weights(items, len(chunk), code, stream()), "pack_weights")
+    key = (code,) + tuple((w.data_ptr(), w.shape, role, stride) for w, role, stride in specs)
+    plan = _PACK_PLANS.get(key)
+    if plan is None:
+        metas, sizes = [], []
+        for w, role, stride in specs:
+            N.require_device(w, "weight")
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                raise N.Ru3dError("ru3d: weights must be contiguous float32 parameters")
+            k = w.shape[2]
+            if role in (N.ROLE_CONVT_FWD, N.ROLE_CONVT_DGRAD):
+                cin, cout, stride = w.shape[0], w.shape[1], 2
+            else:
+                cout, cin = w.shape[0], w.shape[1]
+            nbytes = N.lib.ru3d_packed_weight_bytes(cout, cin, k, stride, role, code)
+            if nbytes == 0:
+                raise N.Ru3dError("ru3d: cannot pack weight of shape %s" % (tuple(w.shape),))
+            metas.append((w.data_ptr(), cout, cin, k, stride, role))
+            sizes.append((nbytes + 255) // 256 * 256)
+        offs, off = [], 0
+        for sz in sizes:
+            offs.append(off)
+            off += sz
+        chunks = []
+        for i0 in range(0, len(metas), N.PACK_MAX):
+            chunk = metas[i0:i0 + N.PACK_MAX]
+            items = (N.PackItem * len(chunk))()
+            for j, (src, cout, cin, k, stride, role) in enumerate(chunk):
+                items[j] = N.PackItem(src, 0, cout, cin, k, stride, role)
+            chunks.append((i0, items))
+        plan = (sizes, offs, off, chunks)
+        if len(_PACK_PLANS) > 4096:
+            _PACK_PLANS.clear()
+        _PACK_PLANS[key] = plan
+    sizes, offs, total, chunks = plan
+    buf = torch.empty(total, dtype=torch.uint8, device=specs[0][0].device)
+    base = buf.data_ptr()
+    outs = [buf[o:o + sz] for o, sz in zip(offs, sizes)]
+    st = stream()
+    for i0, items in chunks:
+        for j in range(len(items)):
+            items[j].dst = base + offs[i0 + j]
+        check(N.lib.ru3d_pack_weights(items, len(items), code, st), "pack_weights")
     return outs
 
 
@@ -232,16 +251,19 @@ def in_lrelu_fwd(y, mean, scale, res=None, out=None):
     return out
 
 
-def in_lrelu_bwd(gout, out, y, mean, scale, want_gpre=False, zero_far=False):
+def in_lrelu_bwd(gout, out, y, mean, scale, want_gpre=False, zero_far=False, want_gpre_sum=False):
     n, c, d, h, w = y.shape
     dy = N.new_act(n, c, d, h, w, y.dtype, y.device)
     gpre = N.new_act(n, c, d, h, w, y.dtype, y.device) if want_gpre else None
     dg, do, dyy, ddy = desc(gout), desc(out), desc(y), desc(dy)
     dp = desc(gpre) if want_gpre else None
     ws = N.workspace(N.lib.ru3d_reduce_workspace_bytes(ref(dyy)), y.device)
+    gsum = torch.empty(c, dtype=torch.float32, device=y.device) if (want_gpre and want_gpre_sum) else None
     check(N.lib.ru3d_in_lrelu_bwd(ref(dg), ref(do), ref(dyy), ptr(mean), ptr(scale), ref(ddy), ref(dp), ptr(ws),
-                                  ws.numel(), LRELU_SLOPE, 1 if zero_far else 0, N.dtype_code(y.dtype), stream()),
-          "in_lrelu_bwd")
+                                  ws.numel(), LRELU_SLOPE, 1 if zero_far else 0, ptr(gsum), N.dtype_code(y.dtype),
+                                  stream()), "in_lrelu_bwd")
+    if want_gpre_sum:
+        return dy, gpre, gsum
     return dy, gpre
 
 
@@ -479,13 +501,14 @@ class ResBlockFn(torch.autograd.Function):
         stride = ctx.stride
         gz = as_grad(gz, sd)
         # lrelu(IN(y2) + skip): dy2 and the pre-activation gradient (= d/dskip)
-        dy2, gpre = in_lrelu_bwd(gz, z, y2, mean2, scale2, want_gpre=True)
+        # sum(gpre) - the skip conv's bias gradient - comes out of the same reduction
+        dy2, gpre, gbs_sum = in_lrelu_bwd(gz, z, y2, mean2, scale2, want_gpre=True, want_gpre_sum=True)
         gws = gbs = None
         with _OnSide(dev):
             gw2 = conv_wgrad(a1, dy2, 3, 1)
             if ctx.has_skip_conv:
                 gws = conv_wgrad(x, gpre, 1, stride)
-                gbs = channel_sum(gpre)
+                gbs = gbs_sum
         gb2 = None   # a bias that feeds InstanceNorm has an identically zero gradient: reported as "no gradient"
         da1 = conv_dgrad(dy2, pw2d, tuple(a1.shape), 3, 1)
         dy1, _ = in_lrelu_bwd(da1, a1, y1, mean1, scale1)

@@ -218,6 +218,16 @@ __global__ __launch_bounds__(256) void bwd_finalize_kernel(const double* __restr
     m12[2 * i + 1] = (float)(t2 * invV);
 }
 
+// sum over n and voxels of gpre from the per-sample means m1 = mean_v(gpre): out[c] = V * sum_n m1[n][c]
+__global__ __launch_bounds__(256) void gpre_sum_kernel(const float* __restrict__ m12, int N, int C, double V,
+                                                       float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int n = 0; n < N; n++) s += (double)m12[2 * (n * C + c)];
+    out[c] = (float)(s * V);
+}
+
 __global__ __launch_bounds__(256) void chansum_finalize_kernel(const double* __restrict__ part, int chunks, int C,
                                                                int N, float* __restrict__ out) {
     const int c = blockIdx.x * FIN_CX + threadIdx.x % FIN_CX;
@@ -429,7 +439,7 @@ extern "C" int ru3d_in_lrelu_fwd(const ru3d_tensor* y, const float* mean, const 
 template <typename T>
 static int in_bwd_impl(const ru3d_tensor* gout, const ru3d_tensor* out, const ru3d_tensor* y, const float* mean,
                        const float* scale, const ru3d_tensor* dy, const ru3d_tensor* gpre, void* ws, float slope,
-                       int zero_far, hipStream_t st) {
+                       int zero_far, float* gpre_sum, hipStream_t st) {
     const int64_t V = (int64_t)y->d * y->h * y->w;
     const int vec = pick_vec<T>(y->c, {gout, out, y, dy, gpre});
     ChanLoop cl = make_chanloop(V, y->c, vec, 64, y->n);
@@ -453,6 +463,12 @@ static int in_bwd_impl(const ru3d_tensor* gout, const ru3d_tensor* out, const ru
                        y->c, NC, 1.0 / (double)V, m12);
     rc = ru3d_check_launch("in_lrelu_bwd_finalize");
     if (rc) return rc;
+    if (gpre_sum) {
+        hipLaunchKernelGGL(gpre_sum_kernel, dim3((y->c + 255) / 256), dim3(256), 0, st, (const float*)m12, y->n, y->c,
+                           (double)V, gpre_sum);
+        rc = ru3d_check_launch("in_lrelu_bwd_gpre_sum");
+        if (rc) return rc;
+    }
     ChanLoop ca = make_chanloop(V, y->c, vec, 16, y->n);
     dim3 grida(ca.chunks, y->n, (ca.G + ca.Gb - 1) / ca.Gb);
 #define CALL(TT, VV)                                                                                                  \
@@ -474,7 +490,8 @@ static int in_bwd_impl(const ru3d_tensor* gout, const ru3d_tensor* out, const ru
 extern "C" int ru3d_in_lrelu_bwd(const ru3d_tensor* gout, const ru3d_tensor* out, const ru3d_tensor* y,
                                  const float* mean, const float* scale, const ru3d_tensor* dy,
                                  const ru3d_tensor* gpre, void* ws, size_t ws_bytes, float slope, int zero_far,
-                                 int dtype, void* stream) {
+                                 float* gpre_sum, int dtype, void* stream) {
+    RU3D_REQUIRE(!gpre_sum || gpre, "in_lrelu_bwd: gpre_sum needs the residual form (gpre != NULL)");
     RU3D_REQUIRE(tensor_ok(gout) && tensor_ok(out) && tensor_ok(y) && tensor_ok(dy), "in_lrelu_bwd: bad tensor");
     RU3D_REQUIRE(same_shape(y, gout) && same_shape(y, out) && same_shape(y, dy), "in_lrelu_bwd: shape mismatch");
     RU3D_REQUIRE(!gpre || (tensor_ok(gpre) && same_shape(y, gpre)), "in_lrelu_bwd: bad gpre");
@@ -483,9 +500,9 @@ extern "C" int ru3d_in_lrelu_bwd(const ru3d_tensor* gout, const ru3d_tensor* out
                  reduce_ws_bytes(y));
     RU3D_REQUIRE((int64_t)y->d * y->h * y->w < (1ll << 31), "in_lrelu_bwd: sample too large");
     if (dtype == RU3D_F32)
-        return in_bwd_impl<float>(gout, out, y, mean, scale, dy, gpre, ws, slope, zero_far, as_stream(stream));
+        return in_bwd_impl<float>(gout, out, y, mean, scale, dy, gpre, ws, slope, zero_far, gpre_sum, as_stream(stream));
     if (dtype == RU3D_BF16)
-        return in_bwd_impl<bf16>(gout, out, y, mean, scale, dy, gpre, ws, slope, zero_far, as_stream(stream));
+        return in_bwd_impl<bf16>(gout, out, y, mean, scale, dy, gpre, ws, slope, zero_far, gpre_sum, as_stream(stream));
     return ru3d_fail(-1, "in_lrelu_bwd: bad dtype %d", dtype);
 }
 
