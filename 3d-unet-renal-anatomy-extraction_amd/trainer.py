@@ -18,6 +18,7 @@ What changes underneath:
     rest of backward) and each rank draws its own samples.
   * apex / torchsummary / tensorboard / nibabel are optional.
 """
+import gc
 import math
 import os
 
@@ -222,6 +223,9 @@ class Trainer():
             save_best=, num_workers=, pin_memory=)                          - run_train.py spelling"""
         save_last = legacy.pop('save_last', True)
         save_best = legacy.pop('save_best', True)
+        # keep the interpreter's full collection (it walks everything torch imported, ~90 ms) out of the step loop
+        gc.collect()
+        gc.freeze()
         if args and not isinstance(args[0], (int, np.integer)):
             self.dataset = args[0]
             args = args[1:]

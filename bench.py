@@ -16,6 +16,7 @@ Extra objects in that line:
                 sample of the same workload (rank 0, N == 1 only).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -137,6 +138,10 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # the interpreter's full (generation-2) collection walks every object torch imported - ~90 ms, once, a few steps
+    # into the process; park the startup objects in the permanent generation before the timed region
+    gc.collect()
+    gc.freeze()
     probe = None
     if not args.no_probe:
         probe = ops.Probe(cin=args.features, cout=args.features, k=3, stride=1,
