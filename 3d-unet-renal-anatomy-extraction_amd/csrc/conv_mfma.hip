@@ -67,6 +67,8 @@ struct MfmaConvArgs {
     int flip;
     int nblk;              // spatial tiles * N (grid.x)
     float* stat_slab;      // optional: per-(workgroup, wave, n, cout) {sum, sum of squares} of the stored outputs
+    float* part;           // split-K (deep levels): fp32 partial outputs [blockIdx.z][voxel][Cout], no bias/residual
+    int ksplit;            // number of 32-channel chunk groups (gridDim.z); 1 = none
 };
 
 // T1 (bijective): consecutive hardware block ids round-robin over the 8 XCDs; give each XCD a contiguous
@@ -125,7 +127,9 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
 
     const bf16x8* wbase = a.w + (int64_t)blockIdx.y * NT * 64 + lane;
     const int nchunks = a.Cin / 32;
-    for (int ch = 0; ch < nchunks; ch++) {
+    // split-K: blockIdx.z owns a contiguous run of 32-channel chunks and writes an fp32 partial
+    const int ch_lo = (nchunks * (int)blockIdx.z) / (int)gridDim.z, ch_hi = (nchunks * ((int)blockIdx.z + 1)) / (int)gridDim.z;
+    for (int ch = ch_lo; ch < ch_hi; ch++) {
         // ---- weight ring prologue (independent of LDS: its latency hides under the staging below)
         bf16x8 wq[WD][NT];
 #pragma unroll
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
                                                      ch * 32 + part * 8);
             stage[i] = v;
         }
-        if (ch) __syncthreads();  // everyone done reading the previous chunk
+        if (ch > ch_lo) __syncthreads();  // everyone done reading the previous chunk
 #pragma unroll
         for (int i = 0; i < NIT; i++) {
             const int c = tid + i * 256;
@@ -200,6 +204,19 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
     for (int m = 0; m < MT; m++) {
         if (od[m] >= a.D || oh[m] >= a.H || ow[m] >= a.W) continue;
         const int64_t vox = (((int64_t)n * a.D + od[m]) * a.H + oh[m]) * a.W + ow[m];
+        if (a.part) {
+            float* pp = a.part + ((int64_t)blockIdx.z * ((int64_t)a.N * a.D * a.H * a.W) + vox) * a.Cout;
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = acc[m][t][q * 4 + i];
+                    *reinterpret_cast<f32x4*>(pp + co_blk + t * 32 + 8 * q + 4 * (lane >> 5)) = v;
+                }
+            continue;
+        }
 #pragma unroll
         for (int t = 0; t < NT; t++) {
 #pragma unroll
@@ -529,6 +546,59 @@ static int launch_s1_pc(const MfmaConvArgs& a0, bool nt2, hipStream_t st) {
     return ru3d_check_launch("conv3_s1_pc");
 }
 
+// y = bf16(sum_z part[z] + bias) (+ residual): fixed summation order, 8 channels (16 B) per thread
+__global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const float* __restrict__ part, int ksplit, int64_t V,
+                                                                 int Cout, const float* __restrict__ bias,
+                                                                 const bf16* __restrict__ res, int ldr,
+                                                                 bf16* __restrict__ y, int ldy) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int cg = Cout / 8;
+    if (g >= V * cg) return;
+    const int64_t vox = g / cg;
+    const int c0 = (int)(g % cg) * 8;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = bias ? bias[c0 + i] : 0.f;
+    for (int z = 0; z < ksplit; z++) {
+        const float* p = part + ((int64_t)z * V + vox) * Cout + c0;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            v[i] += lo[i];
+            v[4 + i] += hi[i];
+        }
+    }
+    if (res) {
+        float r[8];
+        load_vec<bf16, 8>(res + vox * ldr + c0, r);
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = (float)(bf16)v[i] + r[i];   // same two roundings as the fused epilogues
+    }
+    store_vec<bf16, 8>(y + vox * ldy + c0, v);
+}
+
+// Scratch for split-K partials: one 32 MiB buffer per (device, stream), owned by the library and allocated on first
+// use (the conv entry points have no workspace argument).
+#include <mutex>
+static float* ksplit_scratch(hipStream_t st, size_t bytes) {
+    constexpr size_t CAP = 32u << 20;
+    struct Slot { int dev; hipStream_t st; float* p; };
+    static Slot slots[16];
+    static int nslots = 0;
+    static std::mutex mu;
+    if (bytes > CAP) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < nslots; i++)
+        if (slots[i].dev == dev && slots[i].st == st) return slots[i].p;
+    if (nslots == 16) return nullptr;
+    float* p = nullptr;
+    if (hipMalloc((void**)&p, CAP) != hipSuccess) return nullptr;
+    slots[nslots++] = {dev, st, p};
+    return p;
+}
+
 template <int TD, int TH, int TW, int MT>
 static int launch_s1(const MfmaConvArgs& a0, bool nt2, hipStream_t st) {
     MfmaConvArgs a = a0;
@@ -538,14 +608,21 @@ static int launch_s1(const MfmaConvArgs& a0, bool nt2, hipStream_t st) {
     const int64_t nblk = (int64_t)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
     if (nblk > 0x7fffffff) return ru3d_fail(-1, "conv_mfma: grid too large");
     a.nblk = (int)nblk;
+    const int ks = a.part ? a.ksplit : 1;
     if (nt2) {
-        dim3 grid((unsigned)nblk, a.Cout / 64);
+        dim3 grid((unsigned)nblk, a.Cout / 64, ks);
         hipLaunchKernelGGL((conv3_s1_mfma_kernel<TD, TH, TW, MT, 2>), grid, dim3(256), 0, st, a);
     } else {
-        dim3 grid((unsigned)nblk, a.Cout / 32);
+        dim3 grid((unsigned)nblk, a.Cout / 32, ks);
         hipLaunchKernelGGL((conv3_s1_mfma_kernel<TD, TH, TW, MT, 1>), grid, dim3(256), 0, st, a);
     }
-    return ru3d_check_launch("conv3_s1_mfma");
+    int rc = ru3d_check_launch("conv3_s1_mfma");
+    if (rc || !a.part) return rc;
+    const int64_t V = (int64_t)a.N * a.D * a.H * a.W;
+    const int64_t groups = V * (a.Cout / 8);
+    hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st,
+                       (const float*)a.part, ks, V, a.Cout, a.bias, a.res, a.ldr, a.y, a.ldy);
+    return ru3d_check_launch("conv_ksplit_reduce");
 }
 
 // Tile choice: W decides the tile's aspect; if the 256-voxel x 64-cout decomposition yields fewer than ~2
@@ -584,6 +661,32 @@ static int launch_s1_auto(const MfmaConvArgs& a, hipStream_t st) {
         if (p.wclass == 32) return launch_s1<2, 4, 32, 2>(a, p.nt2, st);
         if (p.wclass == 16) return launch_s1<2, 8, 16, 2>(a, p.nt2, st);
         return launch_s1<4, 8, 8, 2>(a, p.nt2, st);
+    }
+    // deep levels are bound by the weight bytes every workgroup pulls into its CU: when 256-voxel tiles x 32-cout
+    // slices still give one workgroup per CU, they halve that traffic against the 128-voxel tiles
+    if (!p.nt2 && p.nblk_pc * (a.Cout / 32) >= 256) {
+        if (p.wclass == 32) return launch_s1<2, 4, 32, 2>(a, false, st);
+        if (p.wclass == 16) return launch_s1<2, 8, 16, 2>(a, false, st);
+        return launch_s1<4, 8, 8, 2>(a, false, st);
+    }
+    // still fewer than one workgroup per CU (8^3): keep the 256-voxel x 32-cout tiles and split the 32-channel
+    // chunks over gridDim.z; fp32 partials in library scratch, fixed-order reduce with the bias / residual fused
+    static const int ksplit_mode = getenv("RU3D_CONV_KSPLIT") ? atoi(getenv("RU3D_CONV_KSPLIT")) : 1;
+    const int64_t units = p.nblk_pc * (a.Cout / 32);
+    const int nchunks = a.Cin / 32;
+    if (ksplit_mode && !p.nt2 && (a.ldy % 8) == 0 && (!a.res || (a.ldr % 8) == 0) && units < 256 && nchunks >= 2) {
+        int ks = 2;
+        while (ks * 2 <= nchunks && units * ks < 256) ks *= 2;
+        const size_t bytes = (size_t)ks * a.N * a.D * a.H * a.W * a.Cout * sizeof(float);
+        float* scratch = ksplit_scratch(st, bytes);
+        if (scratch) {
+            MfmaConvArgs b = a;
+            b.part = scratch;
+            b.ksplit = ks;
+            if (p.wclass == 32) return launch_s1<2, 4, 32, 2>(b, false, st);
+            if (p.wclass == 16) return launch_s1<2, 8, 16, 2>(b, false, st);
+            return launch_s1<4, 8, 8, 2>(b, false, st);
+        }
     }
     if (p.wclass == 32) return launch_s1<1, 4, 32, 1>(a, p.nt2, st);
     if (p.wclass == 16) return launch_s1<1, 8, 16, 1>(a, p.nt2, st);
@@ -1243,6 +1346,8 @@ int conv_mfma_launch(const void* x, const void* w, const float* bias, const void
     a.Cin = g.Cin; a.Cout = g.Cout; a.ldx = g.ldx; a.ldy = g.ldy; a.ldr = g.ldr;
     a.flip = g.flip;
     a.stat_slab = stat_slab;
+    a.part = nullptr;
+    a.ksplit = 1;
     return launch_s1_auto(a, st);
 }
 
