@@ -259,6 +259,102 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const T* __restrict__ x
     }
 }
 
+// The same gradient on MFMA for bf16 with H % 8 == 0, W % 32 == 0: dW[tap][co] is a GEMM with M = 27 taps (padded to
+// 32), N = 32 couts, K = positions.  A persistent workgroup walks (1 x 8 x 32)-position tiles; per tile it stages the
+// dy rows (row-per-position, read back with the hardware 4x16 transpose) and three copies of the 3 x 10 x 32 input
+// patch, pre-shifted by kw - 1 voxels so that every A fragment (8 consecutive positions of one tap) is one aligned
+// ds_read_b128.  The 4 waves split the 16 k-steps of a tile.  dy is read exactly once; the MFMA time is ~1 % of it.
+#define STEM_MF_BLOCKS 1024
+typedef __attribute__((address_space(3))) bf16x4 stem_lds_bf16x4;
+__device__ __forceinline__ bf16x8 stem_tr_frag(const bf16* p) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((stem_lds_bf16x4*)p);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((stem_lds_bf16x4*)(p + 4 * 32));
+    bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                                              float* __restrict__ part, WgradGeom g, int tiles_h,
+                                                              int tiles_w, int ntiles) {
+    __shared__ __attribute__((aligned(16))) bf16 ds[256 * 32];            // [position][32 co]
+    __shared__ __attribute__((aligned(16))) bf16 xs[(3 * 3 * 10 + 1) * 32];   // [kw][kd][row][32 cols] + a zero row
+    __shared__ float red[4][16][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = blockIdx.y * 32;
+    const int h = lane >> 5, cg = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = lane & 3;
+    const int lane_off = q * 32 + 16 * cg + 4 * p4;
+    // A fragment base of this lane: tap = lane & 31 (rows 27..31 read the zero row)
+    const int tap = lane & 31;
+    const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+    const int abase = tap < 27 ? (((kw * 3 + kd) * 10 + kh) * 32 + 8 * h) : (90 * 32);
+    if (tid < 32) xs[90 * 32 + tid] = (bf16)0.f;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int w0 = (t % tiles_w) * 32;
+        t /= tiles_w;
+        const int h0 = (t % tiles_h) * 8;
+        t /= tiles_h;
+        const int d = t % g.Do;
+        const int n = t / g.Do;
+        __syncthreads();   // previous tile consumed
+        // dy rows: 256 positions x 4 pieces of 16 B
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int c = tid + i * 256;
+            const int f = c >> 2, piece = c & 3;
+            const int64_t pos = (((int64_t)n * g.Do + d) * g.Ho + h0 + (f >> 5)) * g.Wo + w0 + (f & 31);
+            *reinterpret_cast<bf16x8*>(&ds[f * 32 + piece * 8]) =
+                *reinterpret_cast<const bf16x8*>(dy + pos * g.lddy + co0 + piece * 8);
+        }
+        // the three shifted copies of the input patch: xs[kw][kd][r][c] = x[d + kd - 1][h0 + r - 1][w0 + c + kw - 1]
+        for (int e = tid; e < 3 * 3 * 10 * 32; e += 256) {
+            const int c = e & 31, r = (e >> 5) % 10, kk = (e >> 5) / 10;
+            const int kdd = kk % 3, kww = kk / 3;
+            const int id = d + kdd - 1, ih = h0 + r - 1, iw = w0 + c + kww - 1;
+            bf16 v = (bf16)0.f;
+            if (id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                v = x[((((int64_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * g.ldx];
+            xs[e] = v;
+        }
+        __syncthreads();
+        // k-steps 4*wave .. 4*wave + 3: positions f0 = 16 ks + 8 h, row ks >> 1, columns 16 (ks & 1) + 8 h ..
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int ks = wave * 4 + j;
+            const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&xs[abase + (tap < 27 ? ((ks >> 1) * 32 + (ks & 1) * 16) : 0)]);
+            const bf16x8 bfrag = stem_tr_frag(ds + (ks * 16 + 8 * h) * 32 + lane_off);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc, 0, 0, 0);
+        }
+    }
+    // sum the 4 waves' partial tiles in a fixed order; D row = tap = (i & 3) + 8 (i >> 2) + 4 (lane >> 5), col = co
+#pragma unroll
+    for (int i = 0; i < 16; i++) red[wave][i][lane] = acc[i];
+    __syncthreads();
+    for (int e = tid; e < 16 * 64; e += 256) {
+        const int i = e >> 6, ln = e & 63;
+        const float s = (red[0][i][ln] + red[1][i][ln]) + (red[2][i][ln] + red[3][i][ln]);
+        const int tp = (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5), co = ln & 31;
+        if (tp < 27) part[((int64_t)blockIdx.x * 27 + tp) * g.Cout + co0 + co] = s;
+    }
+}
+
+static bool stem_wgrad_mfma_ok(const WgradGeom& g, int dtype) {
+    static const int mode = getenv("RU3D_STEM_MFMA") ? atoi(getenv("RU3D_STEM_MFMA")) : 1;
+    return mode && dtype == RU3D_BF16 && (g.Ho % 8) == 0 && (g.Wo % 32) == 0 && g.Do == g.Di && g.Ho == g.Hi &&
+           g.Wo == g.Wi && g.pad == 1;
+}
+
+static int stem_mfma_blocks(const WgradGeom& g) {
+    const int64_t ntiles = (int64_t)g.N * g.Do * (g.Ho / 8) * (g.Wo / 32);
+    return (int)(ntiles < STEM_MF_BLOCKS ? ntiles : STEM_MF_BLOCKS);
+}
+
 bool stem_wgrad_eligible(const WgradGeom& g) {
     return g.Cin == 1 && g.k == 3 && g.stride == 1 && (g.Cout % 32) == 0 && (g.lddy % 8) == 0 &&
            (int64_t)g.N * g.Do * g.Ho * g.Wo < (1ll << 31);
@@ -269,11 +365,27 @@ static int stem_chunks(const WgradGeom& g) {
     return (int)((P + STEM_CHUNK - 1) / STEM_CHUNK);
 }
 
-size_t stem_wgrad_ws_bytes(const WgradGeom& g) { return (size_t)stem_chunks(g) * 27 * g.Cout * sizeof(float); }
+size_t stem_wgrad_ws_bytes(const WgradGeom& g) {
+    // upper bound over both kernels (the MFMA form writes at most STEM_MF_BLOCKS slabs)
+    const size_t chunks = (size_t)stem_chunks(g) > (size_t)STEM_MF_BLOCKS ? (size_t)stem_chunks(g) : (size_t)STEM_MF_BLOCKS;
+    return chunks * 27 * g.Cout * sizeof(float);
+}
 
 int stem_wgrad_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, const WgradGeom& g,
                       int dtype, hipStream_t st) {
     if (!ws || ws_bytes < stem_wgrad_ws_bytes(g)) return ru3d_fail(-1, "stem_wgrad: workspace too small");
+    if (stem_wgrad_mfma_ok(g, dtype)) {
+        const int blocks = stem_mfma_blocks(g);
+        const int tiles_h = g.Ho / 8, tiles_w = g.Wo / 32;
+        const int64_t ntiles = (int64_t)g.N * g.Do * tiles_h * tiles_w;
+        if (ntiles <= 0x7fffffff) {
+            hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(blocks, g.Cout / 32), dim3(256), 0, st, (const bf16*)x,
+                               (const bf16*)dy, (float*)ws, g, tiles_h, tiles_w, (int)ntiles);
+            int rc = ru3d_check_launch("stem_wgrad_mfma");
+            if (rc) return rc;
+            return wgrad_reduce_launch((const float*)ws, dw, blocks, 27, 1, g.Cout, g.s_o, g.s_i, st);
+        }
+    }
     const int chunks = stem_chunks(g);
     dim3 grid(chunks, g.Cout / 32);
     if (dtype == RU3D_F32)

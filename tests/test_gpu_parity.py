@@ -581,3 +581,26 @@ def test_api_rejects_bad_shapes():
     assert rc < 0 and b"extents" in N.lib.ru3d_last_error()
     with pytest.raises(N.Ru3dError):
         ops.conv_fwd(torch.zeros(1, 8, 4, 4, 4), pw, None, 8, 3, 1)   # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("dims,cout", [((8, 16, 64), 32), ((5, 24, 32), 64), ((6, 10, 20), 32)])
+def test_stem_conv_bf16(dims, cout):
+    """1 -> F stem conv (network.py:541): forward and weight gradient in bf16 vs torch CPU on the rounded operands.
+    The first two shapes take the MFMA weight-gradient kernel (H % 8 == 0, W % 32 == 0), the last the VALU one."""
+    g = torch.Generator().manual_seed(sum(dims) + cout)
+    d, h, w = dims
+    xv = torch.randn(2, 1, d, h, w, generator=g)
+    wt = torch.randn(cout, 1, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    x = ops.as_input(xv.to(DEV), torch.bfloat16)
+    pw = ops.pack_weight(wt.to(DEV), N.ROLE_CONV_FWD, torch.bfloat16, 1)
+    y = ops.conv_fwd(x, pw, b.to(DEV), cout, 3, 1)
+    xr = xv.bfloat16().float()
+    wr = wt.bfloat16().float().requires_grad_(True)
+    ref = torch.nn.functional.conv3d(xr, wr, b, padding=1)
+    _close(y, ref, 2 ** -8, 1e-3, "stem fwd")
+    gy = torch.randn(ref.shape, generator=g)
+    gyd = ops.as_input(gy.to(DEV), torch.bfloat16)
+    gw = ops.conv_wgrad(x, gyd, 3, 1)
+    ref.backward(gy.bfloat16().float())
+    _close(gw, wr.grad, 2e-3, 1e-3, "stem wgrad %s" % (dims,))
