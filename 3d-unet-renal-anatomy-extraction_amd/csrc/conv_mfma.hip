@@ -1413,7 +1413,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3_s1_mfma_kernel(MfmaWgradArgs a)
     const int h = lane >> 5, cg = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = lane & 3;
     const int lane_off = q * 32 + 16 * cg + 4 * p4;   // row q of the 4x16 block, columns 4p..4p+3
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += a.G) {
+    // The NEXT tile's global loads are issued before the MFMA loop of the current one and written to LDS after it:
+    // the staging registers are the second buffer, the load latency hides under 112 MFMAs per wave.
+    constexpr int NIT = (HV * 4 + 255) / 256;
+    bf16x8 sx[NIT], sd[4];
+    auto load_tile = [&](int tile) {
         int tt = tile;
         const int w0 = (tt % a.tiles_w) * TW;
         tt /= a.tiles_w;
@@ -1421,9 +1425,6 @@ __global__ __launch_bounds__(256, 2) void wgrad3_s1_mfma_kernel(MfmaWgradArgs a)
         tt /= a.tiles_h;
         const int d0 = (tt % a.tiles_d) * TD;
         const int n = tt / a.tiles_d;
-        // all global loads first (kept in registers), then the LDS writes: one exposed memory latency per tile
-        constexpr int NIT = (HV * 4 + 255) / 256;
-        bf16x8 sx[NIT], sd[4];
 #pragma unroll
         for (int i = 0; i < NIT; i++) {
             const int c = tid + i * 256;
@@ -1447,7 +1448,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3_s1_mfma_kernel(MfmaWgradArgs a)
                                                      cot * 32 + part * 8);
             sd[i] = v;
         }
-        __syncthreads();   // previous tile fully consumed
+    };
+    auto store_tile = [&]() {
 #pragma unroll
         for (int i = 0; i < NIT; i++) {
             const int c = tid + i * 256;
@@ -1458,7 +1460,15 @@ __global__ __launch_bounds__(256, 2) void wgrad3_s1_mfma_kernel(MfmaWgradArgs a)
             const int c = tid + i * 256;
             *reinterpret_cast<bf16x8*>(&ds[(c >> 2) * 32 + (c & 3) * 8]) = sd[i];
         }
-        __syncthreads();
+    };
+    if ((int)blockIdx.x < a.ntiles) {
+        load_tile(blockIdx.x);
+        store_tile();
+    }
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += a.G) {
+        __syncthreads();   // this tile's rows are in LDS
+        const bool more = tile + a.G < a.ntiles;
+        if (more) load_tile(tile + a.G);
 #pragma unroll
         for (int ks = 0; ks < 16; ks++) {
             // first position of this lane's 8-position half of the k-step: f0 = 16 ks + 8 h
@@ -1483,6 +1493,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3_s1_mfma_kernel(MfmaWgradArgs a)
                 }
             }
         }
+        __syncthreads();   // every wave is done with this tile's rows
+        if (more) store_tile();
     }
     // partial slab: part[((chunk * 27 + tap) * Cin + ci) * Cout + co]; D row = ci, col = co
 #pragma unroll
