@@ -74,6 +74,14 @@ bool slide_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* o
 int conv_slide_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
                       float* stat_slab, hipStream_t st);
 
+// wgrad_slide.hip (3x3x3 stride-1 weight gradient on the large levels: D-sliding plane ring)
+struct WgradSlidePlan {
+    int dsplit, DL, tiles_h, tiles_w, units, G, pairs;
+};
+bool wgrad_slide_plan(const WgradGeom& g, WgradSlidePlan* out);
+size_t wgrad_slide_ws_bytes(const WgradGeom& g);
+int wgrad_slide_launch(const void* x, const void* dy, float* dw, void* ws, const WgradGeom& g, hipStream_t st);
+
 // small_convs.hip (1-channel stem, 2..4-channel head)
 bool stem_fwd_eligible(const ConvGeom& g, int dtype, int y_dtype, const void* res);
 int stem_fwd_launch(const void* x, const void* w, const float* bias, void* y, const ConvGeom& g, int dtype,

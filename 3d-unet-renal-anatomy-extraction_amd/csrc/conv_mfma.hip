@@ -1400,7 +1400,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_s1_mfma_kernel(MfmaWgradArgs a)
     int toff[7];
 #pragma unroll
     for (int t = 0; t < 7; t++) {
-        const int tap = wave + 4 * t;
+        const int tap = wave + 4 * t < 27 ? wave + 4 * t : 26;
         const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
         toff[t] = ((kd * HH + kh) * WW + kw) * 32;
     }
@@ -1486,11 +1486,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3_s1_mfma_kernel(MfmaWgradArgs a)
             }
             const bf16x8 bfrag = tr_frag(ds + f0 * 32 + lane_off);
 #pragma unroll
-            for (int t = 0; t < 7; t++) {
-                if (wave + 4 * t < 27) {
-                    const bf16x8 afrag = tr_frag(xs + hvb * 32 + toff[t] + lane_off);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[t], 0, 0, 0);
-                }
+            for (int t = 0; t < 7; t++) {   // tap 27 (wave 3, t = 6) recomputes tap 26 and is dropped: no branches here
+                const bf16x8 afrag = tr_frag(xs + hvb * 32 + toff[t] + lane_off);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[t], 0, 0, 0);
             }
         }
         __syncthreads();   // every wave is done with this tile's rows
@@ -1602,11 +1600,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_staged_mfma_kernel(StagedWgradAr
                 const bf16x8 bfrag = tr_frag(ds + f0 * 32 + lane_off);
 #pragma unroll
                 for (int t = 0; t < NACC; t++) {
-                    const int tap = wave + 4 * t;
-                    if (tap < 27) {
-                        const bf16x8 afrag = tr_frag(xs + (tap * PT + f0) * 32 + lane_off);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[t], 0, 0, 0);
-                    }
+                    // tap 27 (wave 3, t = 6) recomputes tap 26 and is dropped at the end: no branches between MFMAs
+                    const int tap = wave + 4 * t < 27 ? wave + 4 * t : 26;
+                    const bf16x8 afrag = tr_frag(xs + (tap * PT + f0) * 32 + lane_off);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[t], 0, 0, 0);
                 }
             }
         } else {
@@ -1673,7 +1670,11 @@ static int wgrad_mfma_groups(const WgradGeom& g) {
 }
 
 size_t wgrad_mfma_ws_bytes(const WgradGeom& g) {
-    if (wgrad_is_halo_form(g)) return (size_t)wgrad_mfma_groups(g) * 27 * g.Cin * g.Cout * sizeof(float);
+    if (wgrad_is_halo_form(g)) {
+        const size_t tile = (size_t)wgrad_mfma_groups(g) * 27 * g.Cin * g.Cout * sizeof(float);
+        const size_t slide = wgrad_slide_ws_bytes(g);
+        return tile > slide ? tile : slide;
+    }
     const int slabs = staged_groups(g) * (g.k == 1 ? 4 : 1);
     return (size_t)slabs * g.taps * g.Cin * g.Cout * sizeof(float);
 }
@@ -1712,6 +1713,10 @@ int wgrad_mfma_launch(const void* x, const void* dy, float* dw, void* ws, size_t
     if (!ws || ws_bytes < need) return ru3d_fail(-1, "wgrad_mfma: workspace too small (%zu < %zu)", ws_bytes, need);
     if (!aligned_to(x, 16) || !aligned_to(dy, 16)) return ru3d_fail(-1, "wgrad_mfma: operands must be 16-byte aligned");
     if (!wgrad_is_halo_form(g)) return wgrad_staged_launch(x, dy, dw, ws, g, st);
+    {
+        WgradSlidePlan sp;
+        if (wgrad_slide_plan(g, &sp)) return wgrad_slide_launch(x, dy, dw, ws, g, st);
+    }
     MfmaWgradArgs a;
     a.x = (const bf16*)x;
     a.dy = (const bf16*)dy;

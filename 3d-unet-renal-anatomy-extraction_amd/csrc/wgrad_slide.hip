@@ -1,0 +1,276 @@
+// Weight gradient of the 3x3x3 stride-1 conv on the large levels, D-sliding form (reference: autograd of
+// network.py:391-403 conv1 / conv2):   dW[tap][ci][co] = sum_pos X[pos + tap][ci] * DY[pos][co].
+//
+// wgrad3_s1_mfma_kernel (conv_mfma.hip) stages a (2+2)x(4+2)x(32+2) halo tile of X per 256 positions: 3.2x read
+// amplification, all of it through the ~10 B/clk/CU path that bounds that kernel.  Here a persistent workgroup owns one
+// (32 ci) x (32 co) pair and an (8 x 32) column in (H, W), and slides along D: a ring of 4 X planes (10 x 34 rows of
+// 64 B) stays in LDS, every step loads ONE new X plane and one DY plane (256 rows of 64 B) - 38 KB per 256 positions
+// instead of 68 KB - into registers at the top of the step and stores them at the top of the next one (the ring slot of
+// the plane that just died / the other DY buffer), so a whole step of MFMAs covers the load latency and one barrier per
+// step is enough.  Both operands are K-major in memory (a position's channels are contiguous), so fragments come from
+// row-per-position LDS images through ds_read_b64_tr_b16, as in the tile kernel; the 4 waves split the 27 taps
+// (7/7/7/6) and keep their 32x32 fp32 accumulators in registers for the whole run; one slab per workgroup, reduced in
+// fixed order afterwards (deterministic).
+#include "common.h"
+#include "conv.h"
+
+#include <type_traits>
+
+namespace {
+constexpr int TH = 8, TW = 32, HH = TH + 2, WW = TW + 2;
+constexpr int PROWS = HH * WW;        // 340 rows per X plane
+constexpr int XPLANE = PROWS * 32;    // bf16 elements (64-byte rows, no pad: conflict-free transposed reads)
+constexpr int DPLANE = TH * TW * 32;  // DY plane: 256 rows
+constexpr int NSX = 6;                // X pieces (16 B) staged per thread and plane: 1360 / 256
+constexpr int NSD = 4;                // DY pieces per thread and plane: 1024 / 256
+static_assert((4 * XPLANE + 2 * DPLANE) * 2 <= 160 * 1024, "LDS budget");
+
+struct WSlideArgs {
+    const bf16* x;
+    const bf16* dy;
+    float* part;
+    int N, D, H, W;
+    int Cin, Cout, ldx, lddy;
+    int tiles_h, tiles_w, dsplit, DL, units;   // units per (ci, co) pair
+};
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* p) {
+    // 8 consecutive K (positions) of this lane's channel: two 4-row transposed reads
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * 32));
+    bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return r;
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16 lds[4 * XPLANE + 2 * DPLANE];
+    bf16* const dbuf = lds + 4 * XPLANE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int COT = a.Cout / 32;
+    const int cit = blockIdx.y / COT, cot = blockIdx.y % COT;
+
+    // this wave's taps: wave, wave + 4, ... (tap 27 = none); element offset of the tap inside a plane
+    int toff[7];
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        // tap 27 (wave 3's 7th) does not exist: it recomputes tap 26 and is dropped at the end - the MFMA loop
+        // stays free of branches
+        const int tap = wave + 4 * t < 27 ? wave + 4 * t : 26;
+        toff[t] = (((tap / 3) % 3) * WW + tap % 3) * 32;
+    }
+    f32x16 acc[7];
+#pragma unroll
+    for (int t = 0; t < 7; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
+
+    const int h = lane >> 5, cg = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = lane & 3;
+    const int lane_off = q * 32 + 16 * cg + 4 * p4;   // row q of the 4x16 block, columns 4p..4p+3
+
+    // staging constants: X pieces c = tid + 256 i (row c >> 2 of the plane, piece c & 3); DY pieces likewise
+    int xrel[NSX], xzh[NSX], xzw[NSX];
+#pragma unroll
+    for (int i = 0; i < NSX; i++) {
+        const int c = tid + 256 * i;
+        const bool v = c < PROWS * 4;
+        const int r = v ? (c >> 2) : 0;
+        xzh[i] = v ? r / WW : -100000;
+        xzw[i] = r % WW;
+        xrel[i] = ((r / WW) * a.W + (r % WW)) * a.ldx + (c & 3) * 8;
+    }
+    int drel[NSD];
+#pragma unroll
+    for (int i = 0; i < NSD; i++) {
+        const int c = tid + 256 * i;
+        const int f = c >> 2;
+        drel[i] = ((f / TW) * a.W + (f % TW)) * a.lddy + (c & 3) * 8;
+    }
+
+    for (int u = blockIdx.x; u < a.units; u += gridDim.x) {
+        int t = u;
+        const int w0 = (t % a.tiles_w) * TW;
+        t /= a.tiles_w;
+        const int h0 = (t % a.tiles_h) * TH;
+        t /= a.tiles_h;
+        const int d0 = (t % a.dsplit) * a.DL;
+        const int n = t / a.dsplit;
+
+        bool xok[NSX];
+        int xoff[NSX];
+        const int base_hw = ((h0 - 1) * a.W + (w0 - 1)) * a.ldx + cit * 32;
+#pragma unroll
+        for (int i = 0; i < NSX; i++) {
+            const int gh = h0 - 1 + xzh[i], gw = w0 - 1 + xzw[i];
+            xok[i] = gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+            xoff[i] = xok[i] ? base_hw + xrel[i] : 0;     // out-of-range pieces read the plane's first bytes, zeroed at store
+        }
+        const int64_t xps = (int64_t)a.H * a.W * a.ldx, dps = (int64_t)a.H * a.W * a.lddy;
+        const bf16* dyb = a.dy + ((int64_t)n * a.D * a.H + h0) * (int64_t)a.W * a.lddy + (int64_t)w0 * a.lddy + cot * 32;
+
+        bf16x8 sx[NSX], sd[NSD];
+        auto load_x = [&](int pr) {            // X plane d0 - 1 + pr
+            int d = d0 - 1 + pr;
+            d = d < 0 ? 0 : (d >= a.D ? a.D - 1 : d);
+            const bf16* src = a.x + ((int64_t)n * a.D + d) * xps;
+#pragma unroll
+            for (int i = 0; i < NSX; i++) sx[i] = *reinterpret_cast<const bf16x8*>(src + xoff[i]);
+        };
+        auto store_x = [&](int pr, int slot) {
+            const int d = d0 - 1 + pr;
+            const bool dok = d >= 0 && d < a.D;
+#pragma unroll
+            for (int i = 0; i < NSX; i++) {
+                const int c = tid + 256 * i;
+                const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (xzh[i] >= 0) *reinterpret_cast<bf16x8*>(lds + slot * XPLANE + (c >> 2) * 32 + (c & 3) * 8) = (dok && xok[i]) ? sx[i] : z8;
+            }
+        };
+        auto load_d = [&](int s) {             // DY plane d0 + s
+            const bf16* src = dyb + (int64_t)(d0 + s) * dps;
+#pragma unroll
+            for (int i = 0; i < NSD; i++) sd[i] = *reinterpret_cast<const bf16x8*>(src + drel[i]);
+        };
+        auto store_d = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < NSD; i++) {
+                const int c = tid + 256 * i;
+                *reinterpret_cast<bf16x8*>(dbuf + buf * DPLANE + (c >> 2) * 32 + (c & 3) * 8) = sd[i];
+            }
+        };
+
+        __syncthreads();   // the previous unit has left the ring
+        load_x(0); store_x(0, 0);
+        load_x(1); store_x(1, 1);
+        load_x(2); store_x(2, 2);
+        load_d(0); store_d(0);
+        load_x(3);
+        if (a.DL > 1) load_d(1);
+        __syncthreads();
+
+        auto step = [&](auto phc, int s) {
+            constexpr int PH = decltype(phc)::value;
+            // the plane / DY rows loaded during the previous step go to the ring slot and DY buffer that died with it
+            if (s + 3 <= a.DL + 1) store_x(s + 3, (PH + 3) & 3);
+            if (s + 1 < a.DL) store_d((PH + 1) & 1);
+            if (s + 4 <= a.DL + 1) load_x(s + 4);
+            if (s + 2 < a.DL) load_d(s + 2);
+            const bf16* db = dbuf + (PH & 1) * DPLANE;
+            // fragments of k-step ks + 1 are fetched before the MFMAs of k-step ks (one wave per SIMD: nothing else
+            // hides the LDS latency)
+            bf16x8 bq[2], aq[2][7];
+            auto fetch = [&](auto ksc, int buf) {
+                constexpr int ks = decltype(ksc)::value;
+                // positions f0 = 16 ks + 8 h: row ks >> 1 of the 8 x 32 plane tile, columns 16 (ks & 1) + 8 h ..
+                constexpr int rowb = (ks >> 1) * WW + (ks & 1) * 16;
+                bq[buf] = tr_frag(db + (ks * 16 + 8 * h) * 32 + lane_off);
+#pragma unroll
+                for (int t = 0; t < 7; t++) {
+                    const int tap = wave + 4 * t < 27 ? wave + 4 * t : 26;
+                    const int slot = (PH + tap / 9) & 3;
+                    aq[buf][t] = tr_frag(lds + slot * XPLANE + (rowb + 8 * h) * 32 + toff[t] + lane_off);
+                }
+            };
+            fetch(std::integral_constant<int, 0>{}, 0);
+            static_for<0, 16>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value;
+                if constexpr (ks + 1 < 16) fetch(std::integral_constant<int, ks + 1>{}, (ks + 1) & 1);
+#pragma unroll
+                for (int t = 0; t < 7; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks & 1][t], bq[ks & 1], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            __syncthreads();
+        };
+        for (int s4 = 0; s4 < a.DL; s4 += 4) {
+            step(std::integral_constant<int, 0>{}, s4);
+            step(std::integral_constant<int, 1>{}, s4 + 1);
+            step(std::integral_constant<int, 2>{}, s4 + 2);
+            step(std::integral_constant<int, 3>{}, s4 + 3);
+        }
+    }
+    // partial slab: part[((slab * 27 + tap) * Cin + ci) * Cout + co]; D row = ci, col = co
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        const int tap = wave + 4 * t;
+        if (tap < 27) {
+            float* pp = a.part + ((int64_t)blockIdx.x * 27 + tap) * a.Cin * a.Cout;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int ci = cit * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                const int co = cot * 32 + (lane & 31);
+                pp[(int64_t)ci * a.Cout + co] = acc[t][i];
+            }
+        }
+    }
+}
+}  // namespace
+
+// units per pair = N x dsplit x (H/8) x (W/32); G persistent workgroups per pair (= slabs), pairs on grid.y.
+bool wgrad_slide_plan(const WgradGeom& g, WgradSlidePlan* out) {
+    static const int mode = getenv("RU3D_WGRAD_SLIDE") ? atoi(getenv("RU3D_WGRAD_SLIDE")) : 1;
+    if (!mode || g.k != 3 || g.stride != 1 || (g.Cin % 32) || (g.Cout % 32) || (g.Ho % TH) || (g.Wo % TW)) return false;
+    if (g.Do != g.Di || g.Ho != g.Hi || g.Wo != g.Wi || (g.ldx % 8) || (g.lddy % 8)) return false;
+    if ((int64_t)g.Do * g.Ho * g.Wo * (g.ldx > g.lddy ? g.ldx : g.lddy) >= (1ll << 31)) return false;
+    const int pairs = (g.Cin / 32) * (g.Cout / 32);
+    if (pairs > 8) return false;
+    const int64_t cols = (int64_t)g.N * (g.Ho / TH) * (g.Wo / TW);
+    const int gmax = 256 / pairs;             // one workgroup per CU in total
+    int64_t best_cost = -1;
+    int best = 0;
+    for (int ds = 1; ds <= g.Do / 8; ds++) {
+        if (g.Do % ds) continue;
+        const int dl = g.Do / ds;
+        if (dl % 4) continue;
+        const int64_t units = cols * ds;
+        const int64_t gx = units < gmax ? units : gmax;
+        const int64_t cost = ((units + gx - 1) / gx) * (dl + 4);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = ds;
+        }
+    }
+    if (!best) return false;
+    const int64_t units = cols * best;
+    const double ideal = (double)cols * pairs * g.Do / 256.0;
+    if (units * pairs < 192 || (double)best_cost > 1.5 * ideal + 8) return false;
+    out->dsplit = best;
+    out->DL = g.Do / best;
+    out->tiles_h = g.Ho / TH;
+    out->tiles_w = g.Wo / TW;
+    out->units = (int)units;
+    out->G = (int)(units < gmax ? units : gmax);
+    out->pairs = pairs;
+    return true;
+}
+
+size_t wgrad_slide_ws_bytes(const WgradGeom& g) {
+    WgradSlidePlan p;
+    if (!wgrad_slide_plan(g, &p)) return 0;
+    return (size_t)p.G * 27 * g.Cin * g.Cout * sizeof(float);
+}
+
+int wgrad_slide_launch(const void* x, const void* dy, float* dw, void* ws, const WgradGeom& g, hipStream_t st) {
+    WgradSlidePlan p;
+    if (!wgrad_slide_plan(g, &p)) return ru3d_fail(-1, "wgrad_slide: shape not supported");
+    WSlideArgs a;
+    a.x = (const bf16*)x;
+    a.dy = (const bf16*)dy;
+    a.part = (float*)ws;
+    a.N = g.N; a.D = g.Do; a.H = g.Ho; a.W = g.Wo;
+    a.Cin = g.Cin; a.Cout = g.Cout; a.ldx = g.ldx; a.lddy = g.lddy;
+    a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w; a.dsplit = p.dsplit; a.DL = p.DL; a.units = p.units;
+    hipLaunchKernelGGL(wgrad3_s1_slide_kernel, dim3(p.G, p.pairs), dim3(256), 0, st, a);
+    int rc = ru3d_check_launch("wgrad3_s1_slide");
+    if (rc) return rc;
+    return wgrad_reduce_launch((const float*)ws, dw, p.G, 27, g.Cin, g.Cout, g.s_o, g.s_i, st);
+}
