@@ -85,8 +85,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # rehearsal knobs (one-GPU box): RU3D_DIST_BACKEND=gloo RU3D_ONE_DEVICE=1 runs every rank on cuda:0 over gloo, so
+        # the multi-rank code path (GradSync buckets, fused Adam on aliased gradients) is exercised without RCCL
+        backend = os.environ.get("RU3D_DIST_BACKEND", "nccl")
+        if os.environ.get("RU3D_ONE_DEVICE") == "1":
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if world > 1 else 0)
