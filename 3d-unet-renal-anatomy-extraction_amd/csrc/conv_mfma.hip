@@ -916,6 +916,146 @@ __global__ __launch_bounds__(256) void conv_direct_mfma_kernel(DirectArgs a) {
     }
 }
 
+// Gather form on the large levels (3x3x3 stride-2 pooling conv / ConvTranspose input gradient, 1x1x1 convs), second
+// take: the kernel above recomputes a lane's input coordinates and bounds for every (tap, k-step) and reloads the
+// weight fragment for each of its two column tiles.  Here the per-lane work of an iteration is one bit test and one
+// 64-bit add (the lane's base address and its 27-bit mask of in-range taps are computed once; the tap's address delta
+// is wave-uniform; out-of-range lanes read a 16-byte zero block), the two column tiles share every weight fragment, and
+// the fragments of iteration j + 1 are in flight while iteration j's MFMAs issue.
+template <int NT>
+__global__ __launch_bounds__(256) void conv_gather_mfma_kernel(DirectArgs a, const bf16* __restrict__ zero16) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NTT = a.Cout / 32, KS = a.Cin / 16;
+    const int co_blk = blockIdx.y * (NT * 32);
+    const int taps = a.k * a.k * a.k;
+
+    int n_[2], od[2], oh[2], ow[2];
+    bool valid[2];
+    const bf16* xbase[2];
+    uint32_t mask[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const int64_t v = (int64_t)blockIdx.x * 256 + (wave * 2 + m) * 32 + (lane & 31);
+        valid[m] = v < a.total;
+        const int64_t vv = valid[m] ? v : 0;
+        ow[m] = (int)(vv % a.Wo);
+        int64_t t = vv / a.Wo;
+        oh[m] = (int)(t % a.Ho);
+        t /= a.Ho;
+        od[m] = (int)(t % a.Do);
+        n_[m] = (int)(t / a.Do);
+        const int id0 = od[m] * a.stride - a.pad, ih0 = oh[m] * a.stride - a.pad, iw0 = ow[m] * a.stride - a.pad;
+        // address of tap (0,0,0) - may lie outside the tensor, only dereferenced for taps whose mask bit is set
+        xbase[m] = a.x + ((((int64_t)n_[m] * a.Di + id0) * a.Hi + ih0) * a.Wi + iw0) * (int64_t)a.ldx + (lane >> 5) * 8;
+        uint32_t mk = 0;
+        for (int kd = 0; kd < a.k; kd++)
+            for (int kh = 0; kh < a.k; kh++)
+                for (int kw = 0; kw < a.k; kw++) {
+                    const int id = id0 + kd, ih = ih0 + kh, iw = iw0 + kw;
+                    const bool inb = valid[m] && id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+                    mk |= (inb ? 1u : 0u) << ((kd * a.k + kh) * a.k + kw);
+                }
+        mask[m] = mk;
+    }
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; m++)
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[m][t][i] = 0.f;
+
+    const int T = taps * KS;
+    auto fetch = [&](int j, bf16x8 (&xb)[2], bf16x8 (&wa)[NT]) {
+        const int tap = j / KS, ks = j - tap * KS;                     // wave-uniform
+        const int kw = tap % a.k, kh = (tap / a.k) % a.k, kd = tap / (a.k * a.k);
+        const int64_t delta = (((int64_t)kd * a.Hi + kh) * a.Wi + kw) * a.ldx + ks * 16;
+        const int wtap = a.flip ? taps - 1 - tap : tap;
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const bf16* p = ((mask[m] >> tap) & 1u) ? xbase[m] + delta : zero16;
+            xb[m] = *reinterpret_cast<const bf16x8*>(p);
+        }
+        const bf16x8* wrow = a.w + (((int64_t)wtap * KS + ks) * NTT + blockIdx.y * NT) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NT; t++) wa[t] = wrow[t * 64];
+    };
+    auto compute = [&](const bf16x8 (&xb)[2], const bf16x8 (&wa)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int m = 0; m < 2; m++)
+                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[t], xb[m], acc[m][t], 0, 0, 0);
+    };
+    {
+        bf16x8 x0[2], x1[2], w0[NT], w1[NT];
+        fetch(0, x0, w0);
+        int j = 0;
+        for (; j + 1 < T; j += 2) {
+            fetch(j + 1, x1, w1);
+            compute(x0, w0);
+            if (j + 2 < T) fetch(j + 2, x0, w0);
+            compute(x1, w1);
+        }
+        if (j < T) compute(x0, w0);
+    }
+
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        if (!valid[m]) continue;
+        const int64_t vox = (((int64_t)n_[m] * a.Do + od[m]) * a.Ho + oh[m]) * a.Wo + ow[m];
+        const bool far = a.zero_far && (od[m] == a.Do - 1 || oh[m] == a.Ho - 1 || ow[m] == a.Wo - 1);
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int c0 = co_blk + t * 32 + 8 * q + 4 * (lane >> 5);
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[i] = acc[m][t][q * 4 + i];
+                if (a.bias) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + c0);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] += b[i];
+                }
+                if (far) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = 0.f;
+                }
+                if (a.res) {
+                    float r[4];
+                    load_vec<bf16, 4>(a.res + vox * a.ldr + c0, r);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] += r[i];
+                }
+                store_vec<bf16, 4>(a.y + vox * a.ldy + c0, v);
+            }
+        }
+    }
+}
+
+// 16 zero bytes per device for the kernel above (out-of-range lanes load them instead of branching)
+#include <mutex>
+static const bf16* zero_block() {
+    static bf16* z[16] = {nullptr};
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!z[dev]) {
+        bf16* p = nullptr;
+        if (hipMalloc((void**)&p, 256) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipFree(p);
+            return nullptr;
+        }
+        z[dev] = p;
+    }
+    return z[dev];
+}
+
 // The same forms on the deep levels (8^3 .. 16^3 voxels, hundreds of channels): one 256-voxel workgroup per 64 couts
 // leaves tens of workgroups, each walking thousands of dependent (load, MFMA) pairs.  Here a workgroup owns ONE
 // 32-voxel column tile (transposed form: 32 half-resolution positions of one parity class, blockIdx.z) x NT cout
@@ -1304,6 +1444,15 @@ static int launch_direct(const void* x, const void* w, const float* bias, const 
         }
     }
     dim3 grid((unsigned)nblk, g.Cout / (nt2 ? 64 : 32));
+    static const int gather_mode = getenv("RU3D_CONV_GATHER") ? atoi(getenv("RU3D_CONV_GATHER")) : 1;
+    if (gather_mode && !g.transposed && g.k * g.k * g.k <= 27) {
+        const bf16* z16 = zero_block();
+        if (z16) {
+            if (nt2) hipLaunchKernelGGL((conv_gather_mfma_kernel<2>), grid, dim3(256), 0, st, a, z16);
+            else hipLaunchKernelGGL((conv_gather_mfma_kernel<1>), grid, dim3(256), 0, st, a, z16);
+            return ru3d_check_launch("conv_gather_mfma");
+        }
+    }
     if (g.transposed) {
         if (nt2) hipLaunchKernelGGL((conv_direct_mfma_kernel<2, true>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_direct_mfma_kernel<1, true>), grid, dim3(256), 0, st, a);

@@ -457,7 +457,8 @@ def test_mfma_conv_s1_bf16(shape):
 @pytest.mark.parametrize("cin,cout,k,stride,dims", [(32, 64, 3, 2, (7, 9, 11)), (32, 64, 3, 2, (8, 8, 16)),
                                                     (64, 32, 1, 1, (5, 6, 7)), (32, 64, 1, 2, (7, 8, 9)),
                                                     (16, 32, 3, 1, (4, 5, 9)), (48, 96, 3, 2, (6, 6, 6)),
-                                                    (32, 64, 3, 2, (31, 32, 66)), (64, 128, 3, 2, (32, 30, 34))])
+                                                    (32, 64, 3, 2, (31, 32, 66)), (64, 128, 3, 2, (32, 30, 34)),
+                                                    (32, 64, 3, 2, (63, 64, 98)), (64, 32, 1, 1, (40, 48, 56))])
 def test_mfma_direct_conv_forms_bf16(cin, cout, k, stride, dims):
     """Direct-load MFMA kernel: 1x1x1 (stride 1/2), 3x3x3 stride 2, Cin % 32 != 0; forward (gather form),
     input gradient (transposed form for stride 2) with a fused residual, on ragged extents."""
