@@ -12,7 +12,7 @@ def mean_counter(d, counter, kernel_subs):
 
 out = {}
 for name, sub in (("conv3d k3 s1 32->32 on 2x128^3", ("conv3_s1_slide32_kernel", "conv3_s1_pc_kernel", "conv3_s1_mfma_kernel")),
-                  ("wgrad 32->32 on 2x128^3", ("wgrad3_s1_mfma_kernel",))):
+                  ("wgrad 32->32 on 2x128^3", ("wgrad3_s1_slide_kernel", "wgrad3_s1_mfma_kernel"))):
     fetch, n1 = mean_counter(sys.argv[1], "FETCH_SIZE", sub)
     write, n2 = mean_counter(sys.argv[2], "WRITE_SIZE", sub)
     out[name] = {"fetch_size_kib_raw": fetch, "write_size_kib": write, "launches": [n1, n2],
