@@ -56,6 +56,106 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const T* __restrict__ x, 
     store_vec<T, 8>(y + vo * g.ldy + cg * 8, acc);
 }
 
+// The same conv on MFMA for bf16 with H % 8 == 0, W % 32 == 0, Cout % 32 == 0: D[co][pos] = W[co][tap] x patch[tap][pos],
+// K = 27 taps padded to 32 (two k-steps).  A persistent workgroup walks (1 x 8 x 32)-position tiles: the 3 x 10 x 34
+// input patch goes to LDS, every thread expands ONE position into its 32-tap row (im2col in LDS, 80-byte rows), each
+// wave runs 4 MFMAs for its two 32-position rows and writes them through a wave-private patch as 16-byte NDHWC
+// stores.  The VALU form above issues 27 two-byte loads per thread; this one is bound by the 2F bytes it writes.
+#define STEM_FWD_BLOCKS 1024
+__global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
+                                                            const float* __restrict__ bias, bf16* __restrict__ y,
+                                                            ConvGeom g, int tiles_h, int tiles_w, int ntiles) {
+    __shared__ __attribute__((aligned(16))) bf16 xs[3 * 10 * 34 + 4];
+    __shared__ __attribute__((aligned(16))) bf16 pm[256 * 40];         // im2col rows: 32 taps + pad
+    __shared__ __attribute__((aligned(16))) bf16 est[4 * 64 * 40];     // epilogue patches
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int co0 = blockIdx.y * 32;
+    const int h = lane >> 5;
+    // weight fragments: row = co = lane & 31, k = 16 ks + 8 h + j = tap (taps 27..31 are zero)
+    bf16x8 afrag[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int tap = ks * 16 + 8 * h + j;
+            afrag[ks][j] = tap < 27 ? w[tap * g.CoutPad + co0 + (lane & 31)] : (bf16)0.f;
+        }
+    f32x4 bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        bq[q] = bias ? *reinterpret_cast<const f32x4*>(bias + co0 + 8 * q + 4 * h) : z4;
+    }
+    bf16* patch = est + wave * (64 * 40);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int t = tile;
+        const int w0 = (t % tiles_w) * 32;
+        t /= tiles_w;
+        const int h0 = (t % tiles_h) * 8;
+        t /= tiles_h;
+        const int d = t % g.Do;
+        const int n = t / g.Do;
+        __syncthreads();   // previous tile's im2col rows consumed
+        for (int e = tid; e < 3 * 10 * 34; e += 256) {
+            const int c = e % 34, r = (e / 34) % 10, kd = e / 340;
+            const int id = d + kd - 1, ih = h0 + r - 1, iw = w0 + c - 1;
+            bf16 v = (bf16)0.f;
+            if (id >= 0 && id < g.Di && ih >= 0 && ih < g.Hi && iw >= 0 && iw < g.Wi)
+                v = x[((((int64_t)n * g.Di + id) * g.Hi + ih) * g.Wi + iw) * g.ldx];
+            xs[e] = v;
+        }
+        __syncthreads();
+        {   // im2col: thread = position f = (row tid >> 5, column tid & 31)
+            const int hh = tid >> 5, ww = tid & 31;
+            bf16x8 row[4];
+#pragma unroll
+            for (int tap = 0; tap < 32; tap++) {
+                bf16 v = (bf16)0.f;
+                if (tap < 27) v = xs[((tap / 9) * 10 + hh + (tap / 3) % 3) * 34 + ww + tap % 3];
+                row[tap >> 3][tap & 7] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) *reinterpret_cast<bf16x8*>(&pm[tid * 40 + i * 8]) = row[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[i] = 0.f;
+            const int f = (wave * 2 + m) * 32 + (lane & 31);
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(&pm[f * 40 + ks * 16 + 8 * h]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks], bfrag, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[i] = acc[q * 4 + i] + bq[q][i];
+                store_vec<bf16, 4>(patch + (m * 32 + (lane & 31)) * 40 + 8 * q + 4 * h, v);
+            }
+        }
+        const int64_t vrow = (((int64_t)n * g.Do + d) * g.Ho + h0 + 2 * wave) * (int64_t)g.Wo + w0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = (lane >> 2) + 16 * r, part = lane & 3;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + row * 40 + part * 8);
+            const int64_t vox = vrow + (int64_t)(row >> 5) * g.Wo + (row & 31);
+            *reinterpret_cast<bf16x8*>(y + vox * g.ldy + co0 + part * 8) = v;
+        }
+    }
+}
+
+static bool stem_fwd_mfma_ok(const ConvGeom& g, int dtype) {
+    static const int mode = getenv("RU3D_STEM_MFMA") ? atoi(getenv("RU3D_STEM_MFMA")) : 1;
+    return mode && dtype == RU3D_BF16 && (g.Cout % 32) == 0 && (g.Ho % 8) == 0 && (g.Wo % 32) == 0 && g.Do == g.Di &&
+           g.Ho == g.Hi && g.Wo == g.Wi && g.pad == 1 && (g.ldy % 8) == 0;
+}
+
 bool stem_fwd_eligible(const ConvGeom& g, int dtype, int y_dtype, const void* res) {
     return g.Cin == 1 && g.k == 3 && g.stride == 1 && !g.transposed && !g.flip && !g.zero_far && !res &&
            dtype == y_dtype && (g.Cout % 8) == 0 && g.Cout <= 256 && (g.ldy % 8) == 0;
@@ -66,6 +166,16 @@ int stem_fwd_launch(const void* x, const void* w, const float* bias, void* y, co
     const int64_t total = (int64_t)g.N * g.Do * g.Ho * g.Wo * (g.Cout / 8);
     const int64_t blocks = (total + 255) / 256;
     if (blocks > 0x7fffffff) return ru3d_fail(-1, "stem_fwd: grid too large");
+    if (stem_fwd_mfma_ok(g, dtype) && (((uintptr_t)y) % 16) == 0 && (!bias || (((uintptr_t)bias) % 16) == 0)) {
+        const int tiles_h = g.Ho / 8, tiles_w = g.Wo / 32;
+        const int64_t ntiles = (int64_t)g.N * g.Do * tiles_h * tiles_w;
+        if (ntiles <= 0x7fffffff) {
+            const int nb = (int)(ntiles < STEM_FWD_BLOCKS ? ntiles : STEM_FWD_BLOCKS);
+            hipLaunchKernelGGL(stem_fwd_mfma_kernel, dim3(nb, g.Cout / 32), dim3(256), 0, st, (const bf16*)x,
+                               (const bf16*)w, bias, (bf16*)y, g, tiles_h, tiles_w, (int)ntiles);
+            return ru3d_check_launch("stem_fwd_mfma");
+        }
+    }
     const size_t lds = (size_t)28 * g.Cout * sizeof(float);
     if (dtype == RU3D_F32)
         hipLaunchKernelGGL(stem_fwd_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, st, (const float*)x,
