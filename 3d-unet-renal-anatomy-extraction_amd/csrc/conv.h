@@ -82,6 +82,11 @@ bool wgrad_slide_plan(const WgradGeom& g, WgradSlidePlan* out);
 size_t wgrad_slide_ws_bytes(const WgradGeom& g);
 int wgrad_slide_launch(const void* x, const void* dy, float* dw, void* ws, const WgradGeom& g, hipStream_t st);
 
+// wgrad_s2.hip (3x3x3 stride-2 / ConvTranspose weight gradient on the large levels: one parity-split input tile)
+bool wgrad_s2_eligible(const WgradGeom& g);
+size_t wgrad_s2_ws_bytes(const WgradGeom& g);
+int wgrad_s2_launch(const void* x, const void* dy, float* dw, void* ws, const WgradGeom& g, hipStream_t st);
+
 // small_convs.hip (1-channel stem, 2..4-channel head)
 bool stem_fwd_eligible(const ConvGeom& g, int dtype, int y_dtype, const void* res);
 int stem_fwd_launch(const void* x, const void* w, const float* bias, void* y, const ConvGeom& g, int dtype,

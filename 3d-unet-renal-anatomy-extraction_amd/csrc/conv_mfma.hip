@@ -1825,7 +1825,9 @@ size_t wgrad_mfma_ws_bytes(const WgradGeom& g) {
         return tile > slide ? tile : slide;
     }
     const int slabs = staged_groups(g) * (g.k == 1 ? 4 : 1);
-    return (size_t)slabs * g.taps * g.Cin * g.Cout * sizeof(float);
+    const size_t staged = (size_t)slabs * g.taps * g.Cin * g.Cout * sizeof(float);
+    const size_t s2 = wgrad_s2_ws_bytes(g);
+    return staged > s2 ? staged : s2;
 }
 
 static int wgrad_staged_launch(const void* x, const void* dy, float* dw, void* ws, const WgradGeom& g, hipStream_t st) {
@@ -1861,7 +1863,10 @@ int wgrad_mfma_launch(const void* x, const void* dy, float* dw, void* ws, size_t
     const size_t need = wgrad_mfma_ws_bytes(g);
     if (!ws || ws_bytes < need) return ru3d_fail(-1, "wgrad_mfma: workspace too small (%zu < %zu)", ws_bytes, need);
     if (!aligned_to(x, 16) || !aligned_to(dy, 16)) return ru3d_fail(-1, "wgrad_mfma: operands must be 16-byte aligned");
-    if (!wgrad_is_halo_form(g)) return wgrad_staged_launch(x, dy, dw, ws, g, st);
+    if (!wgrad_is_halo_form(g)) {
+        if (wgrad_s2_eligible(g)) return wgrad_s2_launch(x, dy, dw, ws, g, st);
+        return wgrad_staged_launch(x, dy, dw, ws, g, st);
+    }
     {
         WgradSlidePlan sp;
         if (wgrad_slide_plan(g, &sp)) return wgrad_slide_launch(x, dy, dw, ws, g, st);

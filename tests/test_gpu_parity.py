@@ -458,7 +458,8 @@ def test_mfma_conv_s1_bf16(shape):
                                                     (64, 32, 1, 1, (5, 6, 7)), (32, 64, 1, 2, (7, 8, 9)),
                                                     (16, 32, 3, 1, (4, 5, 9)), (48, 96, 3, 2, (6, 6, 6)),
                                                     (32, 64, 3, 2, (31, 32, 66)), (64, 128, 3, 2, (32, 30, 34)),
-                                                    (32, 64, 3, 2, (63, 64, 98)), (64, 32, 1, 1, (40, 48, 56))])
+                                                    (32, 64, 3, 2, (63, 64, 98)), (64, 32, 1, 1, (40, 48, 56)),
+                                                    (32, 64, 3, 2, (32, 32, 128))])
 def test_mfma_direct_conv_forms_bf16(cin, cout, k, stride, dims):
     """Direct-load MFMA kernel: 1x1x1 (stride 1/2), 3x3x3 stride 2, Cin % 32 != 0; forward (gather form),
     input gradient (transposed form for stride 2) with a fused residual, on ragged extents."""
@@ -487,7 +488,8 @@ def test_mfma_direct_conv_forms_bf16(cin, cout, k, stride, dims):
 
 
 @pytest.mark.parametrize("cin,cout,dims", [(64, 32, (3, 4, 5)), (32, 32, (4, 4, 8)), (128, 64, (2, 3, 3)),
-                                           (64, 32, (16, 15, 33)), (128, 64, (16, 31, 16)), (32, 32, (9, 16, 64))])
+                                           (64, 32, (16, 15, 33)), (128, 64, (16, 31, 16)), (32, 32, (9, 16, 64)),
+                                           (64, 32, (16, 16, 32))])
 def test_mfma_convtranspose_bf16(cin, cout, dims):
     """ConvTranspose3d(k3,s2,p1) + far zero pad on the MFMA transposed form (parity classes), its input
     gradient (stride-2 gather) and weight gradient, vs torch CPU on bf16-rounded operands.  The small shapes run
