@@ -1812,7 +1812,8 @@ static int wgrad_mfma_groups(const WgradGeom& g) {
     wgrad_tiles(g, &td, &th, &tw);
     const int64_t ntiles = (int64_t)g.N * ((g.Do + td - 1) / td) * ((g.Ho + th - 1) / th) * ((g.Wo + tw - 1) / tw);
     const int pairs = (g.Cin / 32) * (g.Cout / 32);
-    int64_t G = 512 / pairs;
+    static const int wg_blocks = getenv("RU3D_WGRAD_BLOCKS") ? atoi(getenv("RU3D_WGRAD_BLOCKS")) : 512;
+    int64_t G = wg_blocks / pairs;
     if (G < 1) G = 1;
     if (G > ntiles) G = ntiles;
     return (int)G;

@@ -100,4 +100,6 @@ class Adam(torch.optim.Optimizer):
             check(N.lib.ru3d_adam_multi(ptr(plan["table"]), ptr(plan["block_map"]), plan["nblocks"], _CHUNK,
                                         float(group["lr"]), float(b1), float(b2), float(group["eps"]), bc1, bc2, 1.0,
                                         stream()), "adam_multi")
+        import _ops
+        _ops.WEIGHTS_EPOCH[0] += 1      # packed copies of the weights are stale now
         return loss

@@ -106,3 +106,8 @@ def broadcast_parameters(module, src=0, process_group=None):
     """Identical initial weights on every rank (rank `src`'s)."""
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=process_group)
+    try:                                   # `.data` writes do not bump torch's version counters
+        import _ops
+        _ops.WEIGHTS_EPOCH[0] += 1
+    except ImportError:
+        pass

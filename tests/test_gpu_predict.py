@@ -140,3 +140,51 @@ def test_predict_config2_patch_bf16_vs_fp32_masks():
     print("bf16 vs fp32: max prob diff %.4f, confident voxels %.3f, agreement there %.5f"
           % (np.abs(p32[ok] - p16[ok]).max(), sure.mean(), agree))
     assert agree > 0.999, agree
+
+
+def test_packed_weight_cache_follows_weight_updates():
+    """Inference reuses the packed bf16 weights between windows; the cache must notice every way weights change on this
+    path: the fused optimizer (raw-pointer update), torch in-place ops / load_state_dict, and a new model that happens to
+    be allocated where a freed one lived."""
+    import _ops as ops
+    import loss as L
+    import optim
+    torch.manual_seed(3)
+    x = O.synth_image((1, 1, 32, 32, 32), 5).to(DEV)
+    y = O.phantom_labels(1, (32, 32, 32), 3).to(DEV)
+
+    def fresh(model):
+        ops._PACK_CACHE.clear()
+        with torch.no_grad():
+            return model(x).clone()
+
+    model = network.ResUnet3D(2, 32, 1, 3).to(DEV)
+    network.set_compute_dtype(model, torch.bfloat16)
+    model.eval()
+    with torch.no_grad():
+        a = model(x).clone()
+        b = model(x).clone()                       # served from the cache
+    assert torch.equal(a, b) and len(ops._PACK_CACHE) > 0
+    opt = optim.Adam(model.parameters(), lr=1e-2)
+    L.HybirdLoss()(model(x), y).backward()
+    opt.step()                                     # fused kernel: parameters change behind torch's version counters
+    with torch.no_grad():
+        c = model(x).clone()
+    assert not torch.equal(a, c) and torch.equal(c, fresh(model))
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.5)                            # torch in-place op
+        d = model(x).clone()
+    assert torch.equal(d, fresh(model))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    del model, opt
+    other = network.ResUnet3D(2, 32, 1, 3).to(DEV)   # may land on the freed model's addresses
+    network.set_compute_dtype(other, torch.bfloat16)
+    other.eval()
+    with torch.no_grad():
+        e = other(x).clone()
+    assert torch.equal(e, fresh(other))
+    other.load_state_dict(sd)
+    with torch.no_grad():
+        f = other(x).clone()
+    assert torch.equal(f, d)
