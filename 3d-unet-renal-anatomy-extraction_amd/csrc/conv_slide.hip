@@ -283,6 +283,11 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
                         rq[r] = *reinterpret_cast<const bf16x8*>(rbase + epi_vox(s - 1, r) * a.ldr + (lane & 3) * 8);
                 }
             }
+            // The MFMAs below are inline asm: the compiler's hazard recognizer does not see that they read AGPRs / VGPRs.
+            // Anything it may have written just before (a register restored with v_accvgpr_write, a moved fragment) gets
+            // its wait states here, once per 108 MFMAs; inside the loop every operand comes from a counted LDS read or
+            // from registers written a step ago.
+            asm volatile("s_nop 7\n\ts_nop 7");
             SLIDE_STAMP(PH, 0, s)
             static_for<0, NG>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
