@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
             const bf16* db = dbuf + (PH & 1) * DPLANE;
             // fragments of k-step ks + 1 are fetched before the MFMAs of k-step ks (one wave per SIMD: nothing else
             // hides the LDS latency)
-            bf16x8 bq[2], aq[2][7];
+            bf16x8 bq[3], aq[3][7];
             auto fetch = [&](auto ksc, int buf) {
                 constexpr int ks = decltype(ksc)::value;
                 // positions f0 = 16 ks + 8 h: row ks >> 1 of the 8 x 32 plane tile, columns 16 (ks & 1) + 8 h ..
@@ -181,12 +181,13 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
                 }
             };
             fetch(std::integral_constant<int, 0>{}, 0);
+            fetch(std::integral_constant<int, 1>{}, 1);
             static_for<0, 16>([&](auto ksc) {
                 constexpr int ks = decltype(ksc)::value;
-                if constexpr (ks + 1 < 16) fetch(std::integral_constant<int, ks + 1>{}, (ks + 1) & 1);
+                if constexpr (ks + 2 < 16) fetch(std::integral_constant<int, ks + 2>{}, (ks + 2) % 3);
 #pragma unroll
                 for (int t = 0; t < 7; t++)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks & 1][t], bq[ks & 1], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks % 3][t], bq[ks % 3], acc[t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             });
             __syncthreads();
