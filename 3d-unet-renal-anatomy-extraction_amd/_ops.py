@@ -151,6 +151,17 @@ def set_probe(p):
     _PROBE[0] = p
 
 
+def _conv_ws(dsrc, ddst, k, stride, dtype, device):
+    """(pointer, bytes) of the optional conv scratch (split-K partials on the deepest level), caller-owned."""
+    if k != 3 or stride != 1 or dtype != torch.bfloat16:
+        return None, 0
+    need = N.lib.ru3d_conv3d_workspace_bytes(ref(dsrc), ref(ddst), k, stride, N.dtype_code(dtype))
+    if need == 0:
+        return None, 0
+    buf = N.workspace(need, device)
+    return ptr(buf), buf.numel()
+
+
 def conv_fwd(x, pw, bias, cout, k, stride, res=None, out_dtype=None):
     n, _, d, h, w = x.shape
     out_dtype = out_dtype or x.dtype
@@ -161,8 +172,9 @@ def conv_fwd(x, pw, bias, cout, k, stride, res=None, out_dtype=None):
     dr = desc(res) if res is not None else None
     p = _PROBE[0]
     end = p.begin() if (p is not None and p.match(x.shape[1], cout, k, stride, x.shape[2:])) else None
+    ws, wsn = _conv_ws(dx, dyy, k, stride, x.dtype, x.device)
     check(N.lib.ru3d_conv3d_fwd(ref(dx), ptr(pw), ptr(b), ref(dr), ref(dyy), k, stride, N.dtype_code(x.dtype),
-                                N.dtype_code(out_dtype), stream()), "conv3d_fwd")
+                                N.dtype_code(out_dtype), ws, wsn, stream()), "conv3d_fwd")
     if end is not None:
         end.record()
     return y
@@ -195,8 +207,9 @@ def conv_dgrad(dy, pw, in_shape, k, stride, res=None):
     p = _PROBE[0]
     # the stride-1 input gradient runs the same gather kernel as the forward (taps reversed)
     end = p.begin() if (p is not None and stride == 1 and p.match(dy.shape[1], cin, k, 1, dy.shape[2:])) else None
-    check(N.lib.ru3d_conv3d_dgrad(ref(ddy), ptr(pw), ref(dr), ref(ddx), k, stride, N.dtype_code(dy.dtype), stream()),
-          "conv3d_dgrad")
+    ws, wsn = _conv_ws(ddy, ddx, k, stride, dy.dtype, dy.device)
+    check(N.lib.ru3d_conv3d_dgrad(ref(ddy), ptr(pw), ref(dr), ref(ddx), k, stride, N.dtype_code(dy.dtype), ws, wsn,
+                                  stream()), "conv3d_dgrad")
     if end is not None:
         end.record()
     return dx

@@ -108,7 +108,7 @@ extern "C" int ru3d_pack_weights(const ru3d_pack_item* items, int count, int dty
 
 static int run_conv(const ru3d_tensor* x, const void* w, const float* bias, const ru3d_tensor* res,
                     const ru3d_tensor* y, int k, int stride, int transposed, int flip, int zero_far, int dtype,
-                    int y_dtype, hipStream_t st) {
+                    int y_dtype, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
     ConvGeom g;
     g.N = x->n;
     g.Di = x->d; g.Hi = x->h; g.Wi = x->w; g.Cin = x->c; g.ldx = x->ld;
@@ -121,7 +121,7 @@ static int run_conv(const ru3d_tensor* x, const void* w, const float* bias, cons
     if (head_fwd_eligible(g, dtype, res)) return head_fwd_launch(x->ptr, w, bias, y->ptr, g, dtype, y_dtype, st);
     if (!bias && head_dgrad_eligible(g, dtype, y_dtype, res)) return head_dgrad_launch(x->ptr, w, y->ptr, g, dtype, st);
     if (mfma_conv_eligible(g.Cin, g.Cout, k, dtype, y_dtype) && mfma_conv_geometry_ok(g))
-        return conv_mfma_launch(x->ptr, w, bias, res ? res->ptr : nullptr, y->ptr, g, st);
+        return conv_mfma_launch(x->ptr, w, bias, res ? res->ptr : nullptr, y->ptr, g, st, nullptr, ws, ws_bytes);
     return conv_generic_launch(x->ptr, w, bias, res ? res->ptr : nullptr, y->ptr, g, dtype, y_dtype, st);
 }
 
@@ -130,8 +130,25 @@ static bool res_ok(const ru3d_tensor* res, const ru3d_tensor* y) {
                     res->c == y->c);
 }
 
+// Optional scratch of a conv launch (split-K partials of the deepest level); 0 for most shapes.  The same figure serves
+// the input gradient of a stride-1 conv (call it with (dy, dx)).
+extern "C" size_t ru3d_conv3d_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* y, int k, int stride, int dtype) {
+    if (!tensor_ok(x) || !tensor_ok(y) || dtype != RU3D_BF16 || k != 3 || stride != 1) return 0;
+    if (!mfma_conv_eligible(x->c, y->c, k, dtype, dtype)) return 0;
+    ConvGeom g;
+    g.N = x->n;
+    g.Di = x->d; g.Hi = x->h; g.Wi = x->w; g.Cin = x->c; g.ldx = x->ld;
+    g.Do = y->d; g.Ho = y->h; g.Wo = y->w; g.Cout = y->c; g.ldy = y->ld;
+    g.CoutPad = generic_cout_pad(y->c);
+    g.ldr = 0;
+    g.k = k; g.stride = stride; g.pad = k / 2;
+    g.transposed = 0; g.zero_far = 0; g.flip = 0;
+    return conv_mfma_ws_bytes(g);
+}
+
 extern "C" int ru3d_conv3d_fwd(const ru3d_tensor* x, const void* w_packed, const float* bias, const ru3d_tensor* res,
-                               const ru3d_tensor* y, int k, int stride, int dtype, int y_dtype, void* stream) {
+                               const ru3d_tensor* y, int k, int stride, int dtype, int y_dtype, void* ws,
+                               size_t ws_bytes, void* stream) {
     RU3D_REQUIRE(tensor_ok(x) && tensor_ok(y) && w_packed, "conv3d_fwd: bad tensor/weight");
     RU3D_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "conv3d_fwd: k=%d stride=%d unsupported", k, stride);
     RU3D_REQUIRE(dtype_ok(dtype) && dtype_ok(y_dtype) && !(dtype == RU3D_F32 && y_dtype == RU3D_BF16),
@@ -141,7 +158,7 @@ extern "C" int ru3d_conv3d_fwd(const ru3d_tensor* x, const void* w_packed, const
                  "conv3d_fwd: output extents (%d,%d,%d) do not match input (%d,%d,%d) k=%d s=%d", y->d, y->h, y->w,
                  x->d, x->h, x->w, k, stride);
     RU3D_REQUIRE(res_ok(res, y), "conv3d_fwd: residual shape mismatch");
-    return run_conv(x, w_packed, bias, res, y, k, stride, 0, 0, 0, dtype, y_dtype, as_stream(stream));
+    return run_conv(x, w_packed, bias, res, y, k, stride, 0, 0, 0, dtype, y_dtype, as_stream(stream), ws, ws_bytes);
 }
 
 static ConvGeom fwd_geom(const ru3d_tensor* x, const ru3d_tensor* y, int k, int stride) {
@@ -169,6 +186,8 @@ extern "C" size_t ru3d_conv3d_fwd_in_workspace_bytes(const ru3d_tensor* x, const
         const size_t slab = mfma_conv_stats_slab_bytes(fwd_geom(x, y, k, stride));
         if (slab > need) need = slab;
     }
+    const size_t conv_ws = ru3d_conv3d_workspace_bytes(x, y, k, stride, dtype);
+    if (conv_ws > need) need = conv_ws;
     return need;
 }
 
@@ -187,13 +206,15 @@ extern "C" int ru3d_conv3d_fwd_in(const ru3d_tensor* x, const void* w_packed, co
         if (rc) return rc;
         return mfma_conv_stats_finalize(g, (const float*)ws, drop_scale, eps, mean, scale, as_stream(stream));
     }
-    int rc = ru3d_conv3d_fwd(x, w_packed, bias, nullptr, y, k, stride, dtype, dtype, stream);
+    // the conv's split-K partials and the statistics pass share the workspace (stream order keeps them apart)
+    int rc = ru3d_conv3d_fwd(x, w_packed, bias, nullptr, y, k, stride, dtype, dtype, ws, ws_bytes, stream);
     if (rc) return rc;
     return ru3d_instnorm_stats(y, drop_scale, mean, scale, ws, ws_bytes, eps, dtype, stream);
 }
 
 extern "C" int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* res,
-                                 const ru3d_tensor* dx, int k, int stride, int dtype, void* stream) {
+                                 const ru3d_tensor* dx, int k, int stride, int dtype, void* ws, size_t ws_bytes,
+                                 void* stream) {
     RU3D_REQUIRE(tensor_ok(dy) && tensor_ok(dx) && w_packed, "conv3d_dgrad: bad tensor/weight");
     RU3D_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "conv3d_dgrad: k=%d stride=%d unsupported", k, stride);
     RU3D_REQUIRE(dtype_ok(dtype), "conv3d_dgrad: bad dtype");
@@ -203,7 +224,8 @@ extern "C" int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, co
                  dx->d, dx->h, dx->w, k, stride);
     RU3D_REQUIRE(res_ok(res, dx), "conv3d_dgrad: residual shape mismatch");
     // stride 1: gather form with reversed taps; stride 2: transposed (fractionally strided) form
-    if (stride == 1) return run_conv(dy, w_packed, nullptr, res, dx, k, 1, 0, 1, 0, dtype, dtype, as_stream(stream));
+    if (stride == 1)
+        return run_conv(dy, w_packed, nullptr, res, dx, k, 1, 0, 1, 0, dtype, dtype, as_stream(stream), ws, ws_bytes);
     return run_conv(dy, w_packed, nullptr, res, dx, k, stride, 1, 0, 0, dtype, dtype, as_stream(stream));
 }
 

@@ -56,7 +56,8 @@ size_t mfma_packed_bytes(int cin, int cout, int taps);
 int pack_mfma_launch(const float* src, void* dst, int cin, int cout, int taps, int64_t s_o, int64_t s_i, int flip,
                      hipStream_t st);
 int conv_mfma_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
-                     hipStream_t st, float* stat_slab = nullptr);
+                     hipStream_t st, float* stat_slab = nullptr, void* ws = nullptr, size_t ws_bytes = 0);
+size_t conv_mfma_ws_bytes(const ConvGeom& g);
 bool mfma_conv_can_fuse_stats(const ConvGeom& g);
 size_t mfma_conv_stats_slab_bytes(const ConvGeom& g);
 int mfma_conv_stats_finalize(const ConvGeom& g, const float* slab, const float* drop, float eps, float* mean,

@@ -69,6 +69,8 @@ struct MfmaConvArgs {
     float* stat_slab;      // optional: per-(workgroup, wave, n, cout) {sum, sum of squares} of the stored outputs
     float* part;           // split-K (deep levels): fp32 partial outputs [blockIdx.z][voxel][Cout], no bias/residual
     int ksplit;            // number of 32-channel chunk groups (gridDim.z); 1 = none
+    void* ws;              // caller-owned workspace for the split-K partials (may be null: no split-K)
+    size_t ws_bytes;
 };
 
 // T1 (bijective): consecutive hardware block ids round-robin over the 8 XCDs; give each XCD a contiguous
@@ -577,28 +579,6 @@ __global__ __launch_bounds__(256) void conv_ksplit_reduce_kernel(const float* __
     store_vec<bf16, 8>(y + vox * ldy + c0, v);
 }
 
-// Scratch for split-K partials: one 32 MiB buffer per (device, stream), owned by the library and allocated on first
-// use (the conv entry points have no workspace argument).
-#include <mutex>
-static float* ksplit_scratch(hipStream_t st, size_t bytes) {
-    constexpr size_t CAP = 32u << 20;
-    struct Slot { int dev; hipStream_t st; float* p; };
-    static Slot slots[16];
-    static int nslots = 0;
-    static std::mutex mu;
-    if (bytes > CAP) return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    for (int i = 0; i < nslots; i++)
-        if (slots[i].dev == dev && slots[i].st == st) return slots[i].p;
-    if (nslots == 16) return nullptr;
-    float* p = nullptr;
-    if (hipMalloc((void**)&p, CAP) != hipSuccess) return nullptr;
-    slots[nslots++] = {dev, st, p};
-    return p;
-}
-
 template <int TD, int TH, int TW, int MT>
 static int launch_s1(const MfmaConvArgs& a0, bool nt2, hipStream_t st) {
     MfmaConvArgs a = a0;
@@ -652,6 +632,28 @@ static S1Plan s1_plan(int N, int D, int H, int W, int Cout) {
     return p;
 }
 
+// split-K factor of the deepest level (0/1 = none): the 256-voxel x 32-cout decomposition leaves CUs idle
+static int s1_ksplit(const S1Plan& p, int N, int D, int H, int W, int Cin, int Cout) {
+    static const int ksplit_mode = getenv("RU3D_CONV_KSPLIT") ? atoi(getenv("RU3D_CONV_KSPLIT")) : 1;
+    const int64_t units = p.nblk_pc * (Cout / 32);
+    const int nchunks = Cin / 32;
+    if (!ksplit_mode || !p.small || p.nt2 || units >= 256 || nchunks < 2) return 1;
+    int ks = 2;
+    while (ks * 2 <= nchunks && units * ks < 256) ks *= 2;
+    (void)N; (void)D; (void)H; (void)W;
+    return ks;
+}
+
+// workspace a 3x3x3 stride-1 conv of this geometry can use (split-K partials); 0 = none needed
+size_t conv_mfma_ws_bytes(const ConvGeom& g) {
+    if (!(g.k == 3 && g.stride == 1 && !g.transposed && (g.Cin % 32) == 0 && (g.Cout % 32) == 0)) return 0;
+    SlidePlan sp;
+    if (slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) return 0;
+    const S1Plan p = s1_plan(g.N, g.Do, g.Ho, g.Wo, g.Cout);
+    const int ks = s1_ksplit(p, g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout);
+    return ks > 1 ? (size_t)ks * g.N * g.Do * g.Ho * g.Wo * g.Cout * sizeof(float) : 0;
+}
+
 static int launch_s1_auto(const MfmaConvArgs& a, hipStream_t st) {
     const S1Plan p = s1_plan(a.N, a.D, a.H, a.W, a.Cout);
     if (a.stat_slab && !p.pc) return ru3d_fail(-1, "conv_mfma: fused statistics need the producer/consumer kernel");
@@ -670,18 +672,13 @@ static int launch_s1_auto(const MfmaConvArgs& a, hipStream_t st) {
         return launch_s1<4, 8, 8, 2>(a, false, st);
     }
     // still fewer than one workgroup per CU (8^3): keep the 256-voxel x 32-cout tiles and split the 32-channel
-    // chunks over gridDim.z; fp32 partials in library scratch, fixed-order reduce with the bias / residual fused
-    static const int ksplit_mode = getenv("RU3D_CONV_KSPLIT") ? atoi(getenv("RU3D_CONV_KSPLIT")) : 1;
-    const int64_t units = p.nblk_pc * (a.Cout / 32);
-    const int nchunks = a.Cin / 32;
-    if (ksplit_mode && !p.nt2 && (a.ldy % 8) == 0 && (!a.res || (a.ldr % 8) == 0) && units < 256 && nchunks >= 2) {
-        int ks = 2;
-        while (ks * 2 <= nchunks && units * ks < 256) ks *= 2;
+    // chunks over gridDim.z; fp32 partials in the caller's workspace, fixed-order reduce with the bias / residual fused
+    const int ks = s1_ksplit(p, a.N, a.D, a.H, a.W, a.Cin, a.Cout);
+    if (ks > 1 && (a.ldy % 8) == 0 && (!a.res || (a.ldr % 8) == 0)) {
         const size_t bytes = (size_t)ks * a.N * a.D * a.H * a.W * a.Cout * sizeof(float);
-        float* scratch = ksplit_scratch(st, bytes);
-        if (scratch) {
+        if (a.ws && a.ws_bytes >= bytes && (((uintptr_t)a.ws) % 16) == 0) {
             MfmaConvArgs b = a;
-            b.part = scratch;
+            b.part = (float*)a.ws;
             b.ksplit = ks;
             if (p.wclass == 32) return launch_s1<2, 4, 32, 2>(b, false, st);
             if (p.wclass == 16) return launch_s1<2, 8, 16, 2>(b, false, st);
@@ -922,8 +919,12 @@ __global__ __launch_bounds__(256) void conv_direct_mfma_kernel(DirectArgs a) {
 // 64-bit add (the lane's base address and its 27-bit mask of in-range taps are computed once; the tap's address delta
 // is wave-uniform; out-of-range lanes read a 16-byte zero block), the two column tiles share every weight fragment, and
 // the fragments of iteration j + 1 are in flight while iteration j's MFMAs issue.
+// 16 zero bytes in the code object's data segment: out-of-range lanes load them instead of branching
+__device__ __attribute__((aligned(16))) bf16 g_zero16[8];
+
 template <int NT>
-__global__ __launch_bounds__(256) void conv_gather_mfma_kernel(DirectArgs a, const bf16* __restrict__ zero16) {
+__global__ __launch_bounds__(256) void conv_gather_mfma_kernel(DirectArgs a) {
+    const bf16* const zero16 = g_zero16;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NTT = a.Cout / 32, KS = a.Cin / 16;
@@ -1034,26 +1035,6 @@ __global__ __launch_bounds__(256) void conv_gather_mfma_kernel(DirectArgs a, con
             }
         }
     }
-}
-
-// 16 zero bytes per device for the kernel above (out-of-range lanes load them instead of branching)
-#include <mutex>
-static const bf16* zero_block() {
-    static bf16* z[16] = {nullptr};
-    static std::mutex mu;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    if (!z[dev]) {
-        bf16* p = nullptr;
-        if (hipMalloc((void**)&p, 256) != hipSuccess) return nullptr;
-        if (hipMemset(p, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-            (void)hipFree(p);
-            return nullptr;
-        }
-        z[dev] = p;
-    }
-    return z[dev];
 }
 
 // The same forms on the deep levels (8^3 .. 16^3 voxels, hundreds of channels): one 256-voxel workgroup per 64 couts
@@ -1446,12 +1427,9 @@ static int launch_direct(const void* x, const void* w, const float* bias, const 
     dim3 grid((unsigned)nblk, g.Cout / (nt2 ? 64 : 32));
     static const int gather_mode = getenv("RU3D_CONV_GATHER") ? atoi(getenv("RU3D_CONV_GATHER")) : 1;
     if (gather_mode && !g.transposed && g.k * g.k * g.k <= 27) {
-        const bf16* z16 = zero_block();
-        if (z16) {
-            if (nt2) hipLaunchKernelGGL((conv_gather_mfma_kernel<2>), grid, dim3(256), 0, st, a, z16);
-            else hipLaunchKernelGGL((conv_gather_mfma_kernel<1>), grid, dim3(256), 0, st, a, z16);
-            return ru3d_check_launch("conv_gather_mfma");
-        }
+        if (nt2) hipLaunchKernelGGL((conv_gather_mfma_kernel<2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((conv_gather_mfma_kernel<1>), grid, dim3(256), 0, st, a);
+        return ru3d_check_launch("conv_gather_mfma");
     }
     if (g.transposed) {
         if (nt2) hipLaunchKernelGGL((conv_direct_mfma_kernel<2, true>), grid, dim3(256), 0, st, a);
@@ -1470,7 +1448,7 @@ static bool aligned_to(const void* p, size_t a) { return (((uintptr_t)p) % a) ==
 bool mfma_conv_geometry_ok(const ConvGeom& g) { return !g.transposed || g.stride == 2; }
 
 int conv_mfma_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
-                     hipStream_t st, float* stat_slab) {
+                     hipStream_t st, float* stat_slab, void* ws, size_t ws_bytes) {
     if (!mfma_conv_geometry_ok(g)) return ru3d_fail(-1, "conv_mfma: geometry not supported");
     if ((g.ldx % 8) || (g.ldy % 4) || (res && (g.ldr % 4)) || !aligned_to(x, 16) || !aligned_to(y, 8) ||
         (res && !aligned_to(res, 8)) || (bias && !aligned_to(bias, 16)) || !aligned_to(w, 16))
@@ -1497,6 +1475,8 @@ int conv_mfma_launch(const void* x, const void* w, const float* bias, const void
     a.stat_slab = stat_slab;
     a.part = nullptr;
     a.ksplit = 1;
+    a.ws = ws;
+    a.ws_bytes = ws_bytes;
     return launch_s1_auto(a, st);
 }
 

@@ -87,8 +87,12 @@ int ru3d_pack_weights(const ru3d_pack_item* items, int count, int dtype, void* s
 /* nn.Conv3d(k in {1,3}, stride in {1,2}, padding=k/2) forward (network.py:394-395,403,541-547).
  * y = conv(x) + bias (+ res).  bias (fp32 [Cout]) and res may be NULL.  y_dtype may be RU3D_F32
  * while x is bf16 (the logits head). */
+/* Optional scratch of ru3d_conv3d_fwd / ru3d_conv3d_dgrad (call with (dy, dx) for the latter): split-K partials of the
+ * deepest level; 0 for most shapes.  ws may be NULL (the launch then takes a path that needs none). */
+size_t ru3d_conv3d_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* y, int k, int stride, int dtype);
 int ru3d_conv3d_fwd(const ru3d_tensor* x, const void* w_packed, const float* bias, const ru3d_tensor* res,
-                    const ru3d_tensor* y, int k, int stride, int dtype, int y_dtype, void* stream);
+                    const ru3d_tensor* y, int k, int stride, int dtype, int y_dtype, void* ws,
+                    size_t ws_bytes, void* stream);
 /* The same forward conv FOLLOWED by the InstanceNorm statistics of its output (ResBlock: conv -> dropout ->
  * norm, network.py:411-414): y = conv(x) + bias, then mean / scale exactly as ru3d_instnorm_stats(y, ...)
  * would produce.  On the producer/consumer MFMA kernel the sums are accumulated in the conv epilogue (no
@@ -99,7 +103,8 @@ int ru3d_conv3d_fwd_in(const ru3d_tensor* x, const void* w_packed, const float* 
                        size_t ws_bytes, float eps, void* stream);
 /* input gradient of the same conv: dx = conv_dgrad(dy) (+ res).  w_packed made with ROLE_CONV_DGRAD. */
 int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* res,
-                      const ru3d_tensor* dx, int k, int stride, int dtype, void* stream);
+                      const ru3d_tensor* dx, int k, int stride, int dtype, void* ws, size_t ws_bytes,
+                      void* stream);
 /* weight gradient, written as fp32 in the reference layout [Cout][Cin][k^3] (param.grad). */
 size_t ru3d_conv3d_wgrad_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* dy, int k, int stride, int dtype);
 int ru3d_conv3d_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, float* dw, void* ws, size_t ws_bytes,

@@ -580,7 +580,7 @@ def test_api_rejects_bad_shapes():
     y = N.new_act(1, 8, 5, 4, 4, torch.float32, DEV)   # wrong extent
     pw = ops.pack_weight(torch.zeros(8, 8, 3, 3, 3, device=DEV), N.ROLE_CONV_FWD, torch.float32)
     dx, dy = N.desc(x), N.desc(y)
-    rc = N.lib.ru3d_conv3d_fwd(N.ref(dx), N.ptr(pw), None, None, N.ref(dy), 3, 1, N.F32, N.F32, N.stream())
+    rc = N.lib.ru3d_conv3d_fwd(N.ref(dx), N.ptr(pw), None, None, N.ref(dy), 3, 1, N.F32, N.F32, None, 0, N.stream())
     assert rc < 0 and b"extents" in N.lib.ru3d_last_error()
     with pytest.raises(N.Ru3dError):
         ops.conv_fwd(torch.zeros(1, 8, 4, 4, 4), pw, None, 8, 3, 1)   # CPU tensor: no fallback

@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol():
     assert N.lib.ru3d_packed_weight_bytes(32, 32, 3, 1, N.ROLE_CONV_FWD, N.BF16) > 0
     assert N.lib.ru3d_packed_weight_bytes(32, 32, 5, 1, N.ROLE_CONV_FWD, N.BF16) == 0   # k=5 unsupported
     # argument validation happens before any launch
-    rc = N.lib.ru3d_conv3d_fwd(None, None, None, None, None, 3, 1, N.F32, N.F32, None)
+    rc = N.lib.ru3d_conv3d_fwd(None, None, None, None, None, 3, 1, N.F32, N.F32, None, 0, None)
     assert rc < 0 and b"conv3d_fwd" in N.lib.ru3d_last_error()
 
 
