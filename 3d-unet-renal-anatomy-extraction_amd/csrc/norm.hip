@@ -299,6 +299,9 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(const T* __restrict__
         m1[i] = m12[2 * idx];
         m2[i] = m12[2 * idx + 1];
     }
+    const float inv_slope = 1.f / slope;   // one division per thread, not eight per voxel
+    const bool pow2 = (W & (W - 1)) == 0 && (H & (H - 1)) == 0;
+    const int wshift = 31 - __clz(W);
     const int v0 = blockIdx.x * cl.span;
     int v1 = v0 + cl.span;
     if (v1 > cl.V) v1 = cl.V;
@@ -310,13 +313,17 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(const T* __restrict__
         if (HAS_GPRE) load_vec<T, VEC>(y + row * ldy + cg * VEC, yv);   // no residual: xhat comes from `out`
         bool far = false;
         if (zero_far) {
-            const int w = v % W, h = (v / W) % H, d = v / (W * H);
-            far = (w == W - 1) || (h == H - 1) || (d == D - 1);
+            if (pow2) {   // extents are powers of two almost always: masks instead of three integer divisions per voxel
+                far = ((v & (W - 1)) == W - 1) || (((v >> wshift) & (H - 1)) == H - 1) || (v >= (D - 1) * W * H);
+            } else {
+                const int w = v % W, h = (v / W) % H, d = v / (W * H);
+                far = (w == W - 1) || (h == H - 1) || (d == D - 1);
+            }
         }
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
             const float gp = ov[i] > 0.f ? gv[i] : gv[i] * slope;
-            const float xh = HAS_GPRE ? (yv[i] - mu[i]) * sc[i] : (ov[i] > 0.f ? ov[i] : ov[i] / slope);
+            const float xh = HAS_GPRE ? (yv[i] - mu[i]) * sc[i] : (ov[i] > 0.f ? ov[i] : ov[i] * inv_slope);
             pv[i] = gp;
             dv[i] = far ? 0.f : sc[i] * (gp - m1[i] - xh * m2[i]);
         }
