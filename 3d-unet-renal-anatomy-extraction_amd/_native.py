@@ -6,6 +6,7 @@ device memory, streams and autograd bookkeeping.
 """
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -75,7 +76,13 @@ SIGNATURES = {
     "ru3d_predict_merge": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ru3d_adam_multi": (_i, [_vp, _vp, _i, _i, _f, _f, _f, _f, _f, _f, _f, _vp]),
     "ru3d_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp]),
+    "ru3d_comm_unique_id": (_i, [_vp]),
+    "ru3d_comm_init": (_i, [ctypes.POINTER(_vp), _vp, _i, _i, _i]),
+    "ru3d_comm_allreduce": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    "ru3d_comm_destroy": (_i, [_vp]),
+    "ru3d_flat_cast": (_i, [_vp, _i, _vp, _i, _i64, _f, _vp]),
 }
+COMM_ID_BYTES = 128
 
 
 def _load():
@@ -104,8 +111,20 @@ def check(rc, what=""):
         raise Ru3dError("ru3d %s failed (status %d): %s" % (what, rc, msg))
 
 
+_tls = threading.local()
+
+
+def note_device(device):
+    """Remember the device of the operands of the entry point being assembled (per thread: autograd runs backward
+    on its own threads)."""
+    _tls.device = device
+
+
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """HIP stream handed to the C ABI: torch's current stream OF THE OPERANDS' DEVICE (not of whatever device the
+    calling thread has current).  The library makes that stream's device current for the launch."""
+    dev = getattr(_tls, "device", None)
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
 def dtype_code(dt):
@@ -120,6 +139,7 @@ def require_device(t, what="tensor"):
     if not t.is_cuda:
         raise Ru3dError("ru3d: %s lives on %s; the MI355X-native path has no CPU fallback - move the model "
                         "and its inputs to a HIP device (.cuda())" % (what, t.device))
+    _tls.device = t.device
 
 
 # --------------------------------------------------------------------------- activations
@@ -165,6 +185,7 @@ def desc(t):
     part is memoised: the same few dozen layouts recur every step."""
     if not t.is_cuda:
         require_device(t)
+    _tls.device = t.device
     key = (t.shape, t.stride())
     g = _GEOM.get(key)
     if g is None:

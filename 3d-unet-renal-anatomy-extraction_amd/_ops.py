@@ -86,7 +86,9 @@ def pack_weights(specs, dtype):
     # Unchanged weights (inference: hundreds of windows through the same model) reuse the last packs.  "Unchanged" =
     # torch's version counters (every in-place torch op / load_state_dict bumps them) and WEIGHTS_EPOCH, which the
     # fused optimizer bumps because it updates parameters through raw pointers.
-    ver = tuple(w._version for w, _, _ in specs) + (WEIGHTS_EPOCH[0], torch.cuda.current_stream().cuda_stream)
+    dev0 = specs[0][0].device
+    N.note_device(dev0)
+    ver = tuple(w._version for w, _, _ in specs) + (WEIGHTS_EPOCH[0], torch.cuda.current_stream(dev0).cuda_stream)
     use_cache = not torch.is_grad_enabled()      # inference only: training repacks after every optimizer step anyway
     hit = _PACK_CACHE.get(key) if use_cache else None
     # the entry belongs to these very tensor objects (a freed parameter's address and version can both recur)
@@ -350,6 +352,11 @@ def ndhwc_to_ncdhw(x):
     return out
 
 
+def _dist_rank():
+    d = torch.distributed
+    return d.get_rank() if (d.is_available() and d.is_initialized()) else 0
+
+
 _drop_lock = threading.Lock()
 _drop_counter = [0]
 
@@ -360,7 +367,9 @@ def dropout_scale(n, c, p, device):
         offset = _drop_counter[0]
         _drop_counter[0] += n * c
     out = torch.empty(n * c, dtype=torch.float32, device=device)
-    seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
+    N.note_device(out.device)
+    # one process per GPU: every rank draws its own masks even when all ranks were seeded alike
+    seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * _dist_rank()) & 0xFFFFFFFFFFFFFFFF
     check(N.lib.ru3d_dropout3d_scale(ptr(out), n * c, float(p), ctypes.c_uint64(seed), ctypes.c_uint64(offset),
                                      stream()), "dropout3d_scale")
     return out

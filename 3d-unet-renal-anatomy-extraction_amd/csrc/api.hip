@@ -68,6 +68,7 @@ extern "C" size_t ru3d_packed_weight_bytes(int cout, int cin, int k, int stride,
 
 extern "C" int ru3d_pack_weight(const float* src, void* dst, int cout, int cin, int k, int stride, int role, int dtype,
                                 void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(src && dst, "pack_weight: null pointer");
     RU3D_REQUIRE(cout > 0 && cin > 0 && (k == 1 || k == 3) && (stride == 1 || stride == 2),
                  "pack_weight: bad shape cout=%d cin=%d k=%d stride=%d", cout, cin, k, stride);
@@ -82,6 +83,7 @@ extern "C" int ru3d_pack_weight(const float* src, void* dst, int cout, int cin, 
 }
 
 extern "C" int ru3d_pack_weights(const ru3d_pack_item* items, int count, int dtype, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(items && count > 0 && count <= RU3D_PACK_MAX, "pack_weights: count must be 1..%d", RU3D_PACK_MAX);
     RU3D_REQUIRE(dtype_ok(dtype), "pack_weights: bad dtype");
     PackBatch b;
@@ -149,6 +151,7 @@ extern "C" size_t ru3d_conv3d_workspace_bytes(const ru3d_tensor* x, const ru3d_t
 extern "C" int ru3d_conv3d_fwd(const ru3d_tensor* x, const void* w_packed, const float* bias, const ru3d_tensor* res,
                                const ru3d_tensor* y, int k, int stride, int dtype, int y_dtype, void* ws,
                                size_t ws_bytes, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(x) && tensor_ok(y) && w_packed, "conv3d_fwd: bad tensor/weight");
     RU3D_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "conv3d_fwd: k=%d stride=%d unsupported", k, stride);
     RU3D_REQUIRE(dtype_ok(dtype) && dtype_ok(y_dtype) && !(dtype == RU3D_F32 && y_dtype == RU3D_BF16),
@@ -194,6 +197,7 @@ extern "C" size_t ru3d_conv3d_fwd_in_workspace_bytes(const ru3d_tensor* x, const
 extern "C" int ru3d_conv3d_fwd_in(const ru3d_tensor* x, const void* w_packed, const float* bias, const ru3d_tensor* y,
                                   int k, int stride, int dtype, const float* drop_scale, float* mean, float* scale,
                                   void* ws, size_t ws_bytes, float eps, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(x) && tensor_ok(y) && w_packed && mean && scale && ws, "conv3d_fwd_in: bad argument");
     RU3D_REQUIRE(ws_bytes >= ru3d_conv3d_fwd_in_workspace_bytes(x, y, k, stride, dtype), "conv3d_fwd_in: workspace too small");
     if (fwd_in_fused(x, y, k, stride, dtype)) {
@@ -215,6 +219,7 @@ extern "C" int ru3d_conv3d_fwd_in(const ru3d_tensor* x, const void* w_packed, co
 extern "C" int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* res,
                                  const ru3d_tensor* dx, int k, int stride, int dtype, void* ws, size_t ws_bytes,
                                  void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(dy) && tensor_ok(dx) && w_packed, "conv3d_dgrad: bad tensor/weight");
     RU3D_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "conv3d_dgrad: k=%d stride=%d unsupported", k, stride);
     RU3D_REQUIRE(dtype_ok(dtype), "conv3d_dgrad: bad dtype");
@@ -258,6 +263,7 @@ extern "C" size_t ru3d_conv3d_wgrad_workspace_bytes(const ru3d_tensor* x, const 
 
 extern "C" int ru3d_conv3d_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, float* dw, void* ws, size_t ws_bytes,
                                  int k, int stride, int dtype, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "conv3d_wgrad: k=%d stride=%d unsupported", k, stride);
     RU3D_REQUIRE(wgrad_shapes_ok(x, dy, k, stride), "conv3d_wgrad: x/dy shape mismatch");
     RU3D_REQUIRE(dw && dtype_ok(dtype), "conv3d_wgrad: bad argument");
@@ -276,6 +282,7 @@ static bool convt_shapes_ok(const ru3d_tensor* x, const ru3d_tensor* y) {
 
 extern "C" int ru3d_convtranspose3d_k3s2p1_fwd(const ru3d_tensor* x, const void* w_packed, const float* bias,
                                                const ru3d_tensor* y, int dtype, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(convt_shapes_ok(x, y) && w_packed, "convtranspose3d_fwd: y must have extents 2*x");
     RU3D_REQUIRE(dtype_ok(dtype), "convtranspose3d_fwd: bad dtype");
     return run_conv(x, w_packed, bias, nullptr, y, 3, 2, 1, 0, 1, dtype, dtype, as_stream(stream));
@@ -283,6 +290,7 @@ extern "C" int ru3d_convtranspose3d_k3s2p1_fwd(const ru3d_tensor* x, const void*
 
 extern "C" int ru3d_convtranspose3d_k3s2p1_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* dx,
                                                  int dtype, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(convt_shapes_ok(dx, dy) && w_packed, "convtranspose3d_dgrad: dy must have extents 2*dx");
     RU3D_REQUIRE(dtype_ok(dtype), "convtranspose3d_dgrad: bad dtype");
     // dx[i] = sum_tap dy[2i - 1 + tap] . W[.,.,tap]: a stride-2 gather conv over dy (far planes of dy are zero)
@@ -308,6 +316,7 @@ extern "C" size_t ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes(const ru3d_t
 
 extern "C" int ru3d_convtranspose3d_k3s2p1_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, float* dw, void* ws,
                                                  size_t ws_bytes, int dtype, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(convt_shapes_ok(x, dy), "convtranspose3d_wgrad: dy must have extents 2*x");
     RU3D_REQUIRE(dw && dtype_ok(dtype), "convtranspose3d_wgrad: bad argument");
     WgradGeom g = make_convt_wgrad(x, dy);

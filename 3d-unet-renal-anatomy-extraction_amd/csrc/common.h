@@ -19,6 +19,24 @@ int ru3d_check_launch(const char* what);         // hipGetLastError -> status
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
+// Every launching entry point makes the stream's device current for the duration of the call (PyTorch runs backward
+// on its per-device autograd threads and user code may hold a model on a device other than the thread's current
+// one); a NULL stream means the current device's default stream.  Restores the previous device on exit.
+struct Ru3dDeviceGuard {
+    int prev, want;
+    explicit Ru3dDeviceGuard(void* stream) : prev(-1), want(-1) {
+        if (!stream) return;
+        hipDevice_t dev;
+        if (hipStreamGetDevice((hipStream_t)stream, &dev) != hipSuccess) { (void)hipGetLastError(); return; }
+        want = (int)dev;
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; return; }
+        if (prev != want) (void)hipSetDevice(want);
+    }
+    ~Ru3dDeviceGuard() {
+        if (prev >= 0 && want >= 0 && prev != want) (void)hipSetDevice(prev);
+    }
+};
+
 static inline int64_t nvox(const ru3d_tensor* t) { return (int64_t)t->n * t->d * t->h * t->w; }
 
 static inline int tensor_ok(const ru3d_tensor* t) {

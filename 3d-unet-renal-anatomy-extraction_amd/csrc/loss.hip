@@ -277,6 +277,7 @@ extern "C" int ru3d_loss_fwd(const float* logits, int64_t stride_n, int64_t stri
                              const void* labels, int label_dtype, int n, int64_t v, int num_classes, int kind,
                              float gamma, const float* weight_v, float alpha, float beta, float smooth, void* state,
                              float* loss_out, void* ws, size_t ws_bytes, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(logits && labels && state && loss_out && ws, "loss_fwd: null pointer");
     RU3D_REQUIRE(n > 0 && v > 0, "loss_fwd: empty input");
     RU3D_REQUIRE(num_classes >= 1 && num_classes <= RU3D_MAX_CLASSES, "loss_fwd: %d classes unsupported (max %d)",
@@ -312,6 +313,7 @@ extern "C" int ru3d_loss_bwd(const float* logits, int64_t stride_n, int64_t stri
                              const void* labels, int label_dtype, int n, int64_t v, int num_classes, float gamma,
                              const void* state, const float* grad_out, void* dlogits, int dlogits_dtype,
                              void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(logits && labels && state && dlogits, "loss_bwd: null pointer");
     RU3D_REQUIRE(n > 0 && v > 0, "loss_bwd: empty input");
     RU3D_REQUIRE(num_classes >= 1 && num_classes <= RU3D_MAX_CLASSES, "loss_bwd: %d classes unsupported",
@@ -372,6 +374,7 @@ __global__ void tversky_finalize_kernel(const double* __restrict__ part, int blo
 
 extern "C" int ru3d_tversky(const float* p, const float* g, int64_t count, float alpha, float beta, float smooth,
                             float* out, void* ws, size_t ws_bytes, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(p && g && out && ws && count > 0, "tversky: bad argument");
     int blocks = (int)((count + 2047) / 2048);
     if (blocks > 1024) blocks = 1024;
@@ -404,6 +407,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 extern "C" int ru3d_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
                               float lr, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
                               float grad_scale, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(param && grad && exp_avg && exp_avg_sq && count > 0, "adam_step: bad argument");
     int64_t b = (count + 1023) / 1024;
     if (b > 4096) b = 4096;
@@ -458,6 +462,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const ru3d_adam_tensor*
 extern "C" int ru3d_adam_multi(const ru3d_adam_tensor* tensors, const int32_t* block_map, int nblocks, int chunk_elems,
                                float lr, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
                                float grad_scale, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensors && block_map && nblocks > 0 && chunk_elems >= 1024 && (chunk_elems % 1024) == 0,
                  "adam_multi: bad argument (chunk_elems must be a positive multiple of 1024)");
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, as_stream(stream), tensors, block_map,

@@ -403,6 +403,7 @@ static int stats_impl(const ru3d_tensor* y, const float* drop, float* mean, floa
 
 extern "C" int ru3d_instnorm_stats(const ru3d_tensor* y, const float* drop_scale, float* mean, float* scale, void* ws,
                                    size_t ws_bytes, float eps, int dtype, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(y), "instnorm_stats: bad tensor");
     RU3D_REQUIRE(mean && scale && ws, "instnorm_stats: null output/workspace");
     RU3D_REQUIRE(ws_bytes >= reduce_ws_bytes(y), "instnorm_stats: workspace too small (%zu < %zu)", ws_bytes,
@@ -434,6 +435,7 @@ static int in_fwd_impl(const ru3d_tensor* y, const float* mean, const float* sca
 
 extern "C" int ru3d_in_lrelu_fwd(const ru3d_tensor* y, const float* mean, const float* scale, const ru3d_tensor* res,
                                  const ru3d_tensor* out, float slope, int dtype, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(y) && tensor_ok(out) && same_shape(y, out), "in_lrelu_fwd: bad y/out");
     RU3D_REQUIRE(!res || (tensor_ok(res) && same_shape(y, res)), "in_lrelu_fwd: bad residual");
     RU3D_REQUIRE(mean && scale, "in_lrelu_fwd: null stats");
@@ -498,6 +500,7 @@ extern "C" int ru3d_in_lrelu_bwd(const ru3d_tensor* gout, const ru3d_tensor* out
                                  const float* mean, const float* scale, const ru3d_tensor* dy,
                                  const ru3d_tensor* gpre, void* ws, size_t ws_bytes, float slope, int zero_far,
                                  float* gpre_sum, int dtype, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(!gpre_sum || gpre, "in_lrelu_bwd: gpre_sum needs the residual form (gpre != NULL)");
     RU3D_REQUIRE(tensor_ok(gout) && tensor_ok(out) && tensor_ok(y) && tensor_ok(dy), "in_lrelu_bwd: bad tensor");
     RU3D_REQUIRE(same_shape(y, gout) && same_shape(y, out) && same_shape(y, dy), "in_lrelu_bwd: shape mismatch");
@@ -534,6 +537,7 @@ static int chansum_impl(const ru3d_tensor* t, float* out, void* ws, hipStream_t 
 
 extern "C" int ru3d_channel_sum(const ru3d_tensor* t, float* out, void* ws, size_t ws_bytes, int dtype,
                                 void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(t) && out && ws, "channel_sum: bad argument");
     RU3D_REQUIRE(ws_bytes >= reduce_ws_bytes(t), "channel_sum: workspace too small");
     RU3D_REQUIRE((int64_t)t->d * t->h * t->w < (1ll << 31), "channel_sum: sample too large");
@@ -561,6 +565,7 @@ static int copy_add_impl(const ru3d_tensor* a, const ru3d_tensor* b, const ru3d_
 }
 
 extern "C" int ru3d_copy_channels(const ru3d_tensor* src, const ru3d_tensor* dst, int dtype, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(src) && tensor_ok(dst) && same_shape(src, dst), "copy_channels: bad tensors");
     RU3D_REQUIRE((int64_t)src->d * src->h * src->w < (1ll << 31), "copy_channels: sample too large");
     if (dtype == RU3D_F32) return copy_add_impl<float>(src, nullptr, dst, as_stream(stream));
@@ -570,6 +575,7 @@ extern "C" int ru3d_copy_channels(const ru3d_tensor* src, const ru3d_tensor* dst
 
 extern "C" int ru3d_add(const ru3d_tensor* a, const ru3d_tensor* b, const ru3d_tensor* dst, int dtype,
                         void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(a) && tensor_ok(b) && tensor_ok(dst) && same_shape(a, b) && same_shape(a, dst),
                  "add: bad tensors");
     RU3D_REQUIRE((int64_t)a->d * a->h * a->w < (1ll << 31), "add: sample too large");
@@ -591,6 +597,7 @@ __global__ void cast_f32_kernel(const float* __restrict__ src, int lds, T* __res
 }
 
 extern "C" int ru3d_cast_f32(const ru3d_tensor* src, const ru3d_tensor* dst, int dst_dtype, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(src) && tensor_ok(dst) && same_shape(src, dst), "cast_f32: bad tensors");
     const int64_t rows = nvox(src);
     int64_t b = (rows * src->c + 255) / 256;
@@ -624,6 +631,7 @@ __global__ void dropout_scale_kernel(float* __restrict__ scale, int count, float
 
 extern "C" int ru3d_dropout3d_scale(float* scale, int count, float p, uint64_t seed, uint64_t offset,
                                     void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(scale && count > 0 && p >= 0.f && p < 1.f, "dropout3d_scale: bad argument");
     hipLaunchKernelGGL(dropout_scale_kernel, dim3((count + 255) / 256), dim3(256), 0, as_stream(stream), scale, count,
                        p, seed, offset);
@@ -669,6 +677,7 @@ __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ n
 }
 
 extern "C" int ru3d_ncdhw_to_ndhwc(const float* src, const ru3d_tensor* dst, int dtype, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(src && tensor_ok(dst), "ncdhw_to_ndhwc: bad argument");
     const int64_t V = (int64_t)dst->d * dst->h * dst->w;
     dim3 grid((unsigned)((V + 31) / 32), (dst->c + 31) / 32, dst->n);
@@ -684,6 +693,7 @@ extern "C" int ru3d_ncdhw_to_ndhwc(const float* src, const ru3d_tensor* dst, int
 }
 
 extern "C" int ru3d_ndhwc_to_ncdhw(const ru3d_tensor* src, float* dst, int dtype, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(dst && tensor_ok(src), "ndhwc_to_ncdhw: bad argument");
     const int64_t V = (int64_t)src->d * src->h * src->w;
     dim3 grid((unsigned)((V + 31) / 32), (src->c + 31) / 32, src->n);

@@ -69,6 +69,7 @@ static int accumulate_launch(const ru3d_tensor* t, int dtype, int sample, float*
 
 extern "C" int ru3d_predict_accumulate(const ru3d_tensor* logits, int dtype, int sample, float* acc, float* cnt, int X,
                                        int Y, int Z, int ox, int oy, int oz, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(logits) && acc && cnt, "predict_accumulate: bad argument");
     RU3D_REQUIRE(dtype == RU3D_F32 || dtype == RU3D_BF16, "predict_accumulate: dtype must be f32 or bf16");
     RU3D_REQUIRE(sample >= 0 && sample < logits->n, "predict_accumulate: sample %d outside batch of %d", sample,
@@ -162,6 +163,7 @@ static int merge_launch(const float* acc, const float* cnt, int Y, int Z, int cx
 
 extern "C" int ru3d_predict_merge(const float* acc, const float* cnt, int X, int Y, int Z, int num_classes, int cx,
                                   int cy, int cz, int sx, int sy, int sz, int one_hot, void* out, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(acc && cnt && out, "predict_merge: bad argument");
     RU3D_REQUIRE(num_classes >= 1 && num_classes <= RU3D_PREDICT_MAX_CLASSES, "predict_merge: %d classes (max %d)",
                  num_classes, RU3D_PREDICT_MAX_CLASSES);

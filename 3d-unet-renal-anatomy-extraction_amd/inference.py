@@ -139,6 +139,7 @@ def predict_per_patch(input, model, num_classes=3, patch_size=(96, 96, 96), step
         out = torch.empty(original_shape + (num_classes,), dtype=torch.float32, device=device)
     else:
         out = torch.empty(original_shape, dtype=torch.uint8, device=device)
+    N.note_device(acc.device)
     check(N.lib.ru3d_predict_merge(ptr(acc), ptr(cnt), full[0], full[1], full[2], num_classes, co[0], co[1], co[2],
                                    sx, sy, sz, 1 if one_hot else 0, ptr(out), stream()), "predict_merge")
     return out.cpu().numpy()

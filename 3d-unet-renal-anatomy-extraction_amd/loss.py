@@ -51,6 +51,7 @@ def dice(input, target, alpha=0.5, beta=0.5, smooth=1e-7):
         p = input.detach().reshape(-1).float().contiguous()
         g = target.detach().reshape(-1).float().contiguous()
         out = torch.empty((), dtype=torch.float32, device=p.device)
+        N.note_device(p.device)
         ws = N.workspace(1024 * 3 * 8, p.device)
         check(N.lib.ru3d_tversky(ptr(p), ptr(g), p.numel(), alpha, beta, smooth, ptr(out), ptr(ws), ws.numel(),
                                  stream()), "tversky")
@@ -143,6 +144,7 @@ class _FusedLossFn(torch.autograd.Function):
         if g.dtype != torch.float32 or g.device != x.device:
             g = g.to(device=x.device, dtype=torch.float32)
         g = g.reshape(1).contiguous()
+        N.note_device(x.device)
         dz = torch.empty_like(x)   # preserve_format: same (dense) strides as the logits
         if dz.stride() != x.stride():
             dz = torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device)

@@ -63,6 +63,7 @@ class Adam(torch.optim.Optimizer):
             if not params:
                 continue
             plan = self._plan(gi, group)
+            N.note_device(params[0].device)
             b1, b2 = group["betas"]
             if plan.get("copied") is not None:
                 plan["copied"].synchronize()     # previous step's async H2D of the table has left the host buffer

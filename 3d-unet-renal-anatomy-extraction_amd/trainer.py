@@ -207,12 +207,55 @@ class Trainer():
             writer.close()
         return mean_result
 
+    # ------------------------------------------------------------------ one process per GPU
+    def _enter_distributed(self):
+        """Make the ranks one job (the reference is single-process): rank 0's weights, optimizer hyper-parameters
+        and train/valid split everywhere, gradient averaging on, per-rank sample streams.  Idempotent."""
+        import torch.distributed as dist
+        from parallel import GradSync, broadcast_parameters
+        if self._grad_sync is None:
+            broadcast_parameters(self.model)
+            self._grad_sync = GradSync(self.model)
+        box = [self.train_indices, self.valid_indices, self.current_epoch]
+        dist.broadcast_object_list(box, src=0)
+        self.train_indices, self.valid_indices, self.current_epoch = box
+
+    def _epoch_mean_over_ranks(self, result):
+        """Every rank must feed the scheduler and the best-checkpoint rule the same numbers."""
+        if not _dist_ready() or not result:
+            return result
+        import torch.distributed as dist
+        keys = sorted(result.keys())
+        vals = torch.tensor([[result[k] for k in keys]], dtype=torch.float64)
+        vals = torch.nan_to_num(vals, nan=0.0)
+        flags = torch.tensor([[0.0 if math.isnan(result[k]) else 1.0 for k in keys]], dtype=torch.float64)
+        both = torch.cat([vals * flags, flags]).to(self.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(both)
+        both = both.cpu()
+        return {k: (float(both[0, i] / both[1, i]) if both[1, i] > 0 else float('nan')) for i, k in enumerate(keys)}
+
     # ------------------------------------------------------------------ loaders
     def _loader(self, indices, transform, num_samples, shuffle):
         subset = Subset(self.dataset, indices, transform)
         kwargs = dict(self.dataloader_kwargs)
+        gen = None
+        if _dist_ready():
+            # same split on every rank, different draws: rank r's sampler stream is seeded from the global seed and r
+            import torch.distributed as dist
+            gen = torch.Generator()
+            gen.manual_seed((torch.initial_seed() + 7919 * (dist.get_rank() + 1) + 104729 * self.current_epoch)
+                            % (1 << 63))
         if num_samples is not None:
-            sampler = torch.utils.data.RandomSampler(subset, True, num_samples)
+            sampler = torch.utils.data.RandomSampler(subset, True, num_samples, generator=gen)
+            return torch.utils.data.DataLoader(subset, sampler=sampler, **kwargs)
+        if _dist_ready() and shuffle is False and len(indices) > 0:
+            # validation without resampling: rank r takes every world-th case; the epoch mean is reduced over ranks
+            import torch.distributed as dist
+            part = list(range(dist.get_rank(), len(subset), dist.get_world_size()))
+            if part:
+                return torch.utils.data.DataLoader(torch.utils.data.Subset(subset, part), shuffle=False, **kwargs)
+        if shuffle and gen is not None:
+            sampler = torch.utils.data.RandomSampler(subset, False, generator=gen)
             return torch.utils.data.DataLoader(subset, sampler=sampler, **kwargs)
         return torch.utils.data.DataLoader(subset, shuffle=shuffle, **kwargs)
 
@@ -263,9 +306,8 @@ class Trainer():
             # apex O1 (fp16 convs) in the reference; here: bf16 storage + fp32 accumulate in the HIP kernels
             import network
             network.set_compute_dtype(self.model, torch.bfloat16)
-        if _dist_ready() and self._grad_sync is None:
-            from parallel import GradSync
-            self._grad_sync = GradSync(self.model)
+        if _dist_ready():
+            self._enter_distributed()
         self.progress_bar = tqdm(total=0) if (tqdm is not None and self.progress) else _NullBar()
 
         train_loader = self._loader(self.train_indices, self.train_transform, self.num_samples, True)
@@ -279,6 +321,7 @@ class Trainer():
             result = self.batch_loop(train_loader, is_train=True)
             if valid_loader is not None:
                 result = self.batch_loop(valid_loader, is_train=False)
+            result = self._epoch_mean_over_ranks(result)
             if self.scheduler is not None:
                 if isinstance(self.scheduler, lr_scheduler.ReduceLROnPlateau):
                     self.scheduler.step(result['loss'])

@@ -2,23 +2,31 @@
 """Headline benchmark: train voxels/s of the native 3D U-Net step (BASELINE.json config 2).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One step = forward (train mode, Dropout3d on) + HybirdLoss + backward + gradient all-reduce (N > 1)
-+ Adam(lr=1e-4), on `ResUnet3D(4, 32, 1, 3)`, bf16 storage / fp32 accumulate, 2 x 128^3 synthetic CT
-patches per GPU resident in HBM.  Rank 0 prints ONE JSON line.
+N > 1 without a launcher: this script starts N fresh child ranks itself (torch.distributed.run, one process per GPU)
+before it touches the GPU, and relays rank 0's JSON line.  Under a launcher (WORLD_SIZE set, the driver's
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) it runs as one rank; --gpus must then
+equal WORLD_SIZE.
+
+One step = forward (train mode, Dropout3d on) + HybirdLoss + backward + gradient all-reduce over RCCL (N > 1)
++ Adam(lr=1e-4), on `ResUnet3D(4, 32, 1, 3)`, bf16 storage / fp32 accumulate, 2 x 128^3 synthetic CT patches per GPU
+resident in HBM.  Rank 0 prints ONE JSON line.
 
 Extra objects in that line:
-  roofline      the dominant kernel (3x3x3 conv 32->32 on the 2x128^3 grid; forward and stride-1
-                dgrad launches of the same kernel), timed live with HIP events recorded on the launch
-                stream around each of its launches inside the timed steps.
-  cpu_baseline  the CPU oracle (oracle/unet_oracle.py, kind "port") timed on the host on a bounded
-                sample of the same workload (rank 0, N == 1 only).
+  roofline        the 3x3x3 conv 32->32 on the 2x128^3 grid (forward and stride-1 dgrad launches of the same kernel),
+                  timed live with HIP events recorded on the launch stream around each launch inside the timed steps.
+  roofline_step   the whole step against SURVEY 8(d)'s ALG_FLOPS / ALG_BYTES for the configuration.
+  parity          N == 1: the bf16 model's eval-mode argmax mask against the CPU oracle's (same weights, same input):
+                  per-class Dice (reference `dice`, loss.py:32-48), flipped voxels, flips outside the margin band;
+                  the same for the fp32 parity mode of the HIP path.
+  cpu_baseline    the CPU oracle (oracle/unet_oracle.py, kind "port") timed on the host on a bounded sample of the
+                  same workload (rank 0, N == 1 only): 1 warm-up + 2 timed train steps at bs=1.
 """
 import argparse
 import gc
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,8 +35,6 @@ PKG = os.path.join(ROOT, "3d-unet-renal-anatomy-extraction_amd")
 for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
-
-import torch  # noqa: E402
 
 HBM_PEAK = 8.0e12        # B/s, MI355X spec (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK = 2.5e15  # FLOP/s dense
@@ -39,62 +45,182 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--patch", type=int, default=128)
+    ap.add_argument("--patch", type=int, nargs="+", default=[128], help="one extent (cube) or three (D H W)")
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--features", type=int, default=32)
     ap.add_argument("--pools", type=int, default=4)
     ap.add_argument("--classes", type=int, default=3)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--optimizer", default="fused", choices=["fused", "torch"],
                     help="fused = optim.Adam (ru3d_adam_multi); torch = torch.optim.Adam")
+    ap.add_argument("--checkpoint", action="store_true", help="recompute ResBlock interiors in backward")
+    ap.add_argument("--grad-transport", default=os.environ.get("RU3D_GRAD_TRANSPORT", "fp32"),
+                    choices=["fp32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-torch-adam", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off")
     return ap.parse_args()
 
 
-def cpu_baseline(args):
-    """Oracle (CPU restatement) train step on a bounded sample: 1 x patch^3 instead of batch x patch^3."""
-    from oracle import unet_oracle as O
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: N fresh child processes (this process never touches the GPU)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def conv_plan(pools, features, classes):
+    """(cin, cout, k, stride, level, transposed) of every conv of ResUnet3D (reference network.py:470-565)."""
+    widths = [features << i for i in range(pools + 1)]
+    convs = [(1, features, 3, 1, 0, False), (features, classes, 1, 1, 0, False)]
+
+    def res(cin, cout, stride, level):
+        out = [(cin, cout, 3, stride, level, False), (cout, cout, 3, 1, level, False)]
+        if cin != cout or stride != 1:
+            out.append((cin, cout, 1, stride, level, False))
+        return out
+
+    for lv in range(pools + 1):
+        for i in range(max(lv, 1)):
+            convs += res(widths[lv], widths[lv], 1, lv)
+        if lv < pools:
+            convs += res(widths[lv], widths[lv + 1], 2, lv + 1)                 # pool: output on level lv+1
+            convs.append((widths[lv + 1], widths[lv], 3, 2, lv + 1, True))      # up: input on level lv+1
+            convs += res(2 * widths[lv], widths[lv], 1, lv)                     # decode
+    return convs
+
+
+def alg_work(pools, features, classes, batch, dims, elem):
+    """ALG_FLOPS = 3 * sum 2*MACs, ALG_BYTES = 3 * sum (|in| + |out| + |W|) * elem."""
+    flops = 0.0
+    nbytes = 0.0
+    for cin, cout, k, stride, level, transposed in conv_plan(pools, features, classes):
+        d = [x >> level for x in dims]
+        v = batch * d[0] * d[1] * d[2]            # transposed: input positions; else: output positions
+        macs = v * cin * cout * k ** 3
+        if transposed:
+            vin, vout = v, batch * (2 * d[0] - 1) * (2 * d[1] - 1) * (2 * d[2] - 1)
+        else:
+            vout, vin = v, v * stride ** 3
+        flops += 3 * 2.0 * macs
+        nbytes += 3 * (vin * cin + vout * cout + cin * cout * k ** 3) * elem
+    return flops, nbytes
+
+
+def host_cores():
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    cores = min(cores, int(os.environ.get("RU3D_CPU_THREADS", "16")))   # the GPU box's CPU share per GPU
+    return min(cores, int(os.environ.get("RU3D_CPU_THREADS", "16")))   # the GPU box's CPU share per GPU
+
+
+def cpu_baseline(args, dims):
+    """Oracle (CPU restatement) train steps on a bounded sample: bs=1 instead of bs=2, 1 warm-up + 2 timed."""
+    import torch
+    from oracle import unet_oracle as O
+    cores = host_cores()
     torch.set_num_threads(cores)
-    patch = args.patch if args.patch <= 128 else 128
+    dims = tuple(min(d, 128) for d in dims)
     w = O.init_state_dict(args.pools, args.features, 1, args.classes, seed=0)
-    x = O.synth_image((1, 1, patch, patch, patch), 1234)
-    y = torch.randint(0, args.classes, (1, patch, patch, patch), generator=torch.Generator().manual_seed(1234))
+    x = O.synth_image((1, 1) + dims, 1234)
+    y = torch.randint(0, args.classes, (1,) + dims, generator=torch.Generator().manual_seed(1234))
     state = {}
-    t0 = time.perf_counter()
-    loss, _, grads = O.train_step(w, x, y, args.pools, {"weight_v": [1, 10, 20][:args.classes]})
-    O.adam_step(w, grads, state)
-    dt = time.perf_counter() - t0
-    return {"value": patch ** 3 / dt, "unit": "voxels/s", "cores": cores, "kind": "port",
-            "sample": "1 train step (fwd + HybirdLoss + bwd + Adam) of the same model in fp32 on 1x%d^3 "
-                      "(half of the bs=2 workload), torch-CPU oracle, %.1f s" % (patch, dt)}
+    times = []
+    for i in range(3):
+        t0 = time.perf_counter()
+        loss, _, grads = O.train_step(w, x, y, args.pools, {"weight_v": [1, 10, 20][:args.classes]})
+        O.adam_step(w, grads, state)
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[1:]) / 2
+    vox = dims[0] * dims[1] * dims[2]
+    return {"value": vox / dt, "unit": "voxels/s", "cores": cores, "kind": "port", "batch": 1,
+            "sample": "1 warm-up + 2 timed train steps (fwd + HybirdLoss + bwd + Adam) of the same model in fp32 at "
+                      "bs=1 on 1x%dx%dx%d (half of the bs=2 workload), torch-CPU oracle, %.1f s per step "
+                      "(warm-up %.1f s)" % (dims + (dt, times[0]))}
+
+
+def parity_report(args, model, dims, dev, dtype):
+    """Dice between the HIP path's argmax mask and the CPU oracle's, same weights and input (BASELINE metric's
+    'Dice vs CPU ref'); eval mode (dropout off).  bs=1 of the bench shape, capped at 128^3 for the CPU side."""
+    import torch
+    import network
+    from oracle import unet_oracle as O
+    torch.set_num_threads(host_cores())
+    dims = tuple(min(d, 128) for d in dims)
+    w = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    x = O.synth_image((1, 1) + dims, 4321)
+    with torch.no_grad():
+        ref = O.unet_forward(x, w, args.pools)                 # fp32 CPU oracle logits [1, C, D, H, W]
+    ref_mask = ref.argmax(1)
+    top2 = ref.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1])
+    out = {"input": "1x1x%dx%dx%d synthetic CT patch, weights = the benchmarked model after its timed steps" % dims,
+           "oracle": "oracle.unet_forward fp32 on the host"}
+    was_training = model.training
+    model.eval()
+    for name, dt, band in (("bf16" if dtype != torch.float16 else "fp16", dtype, 0.1), ("fp32", torch.float32, 5e-5)):
+        if dt == torch.float32 and name != "fp32":
+            continue
+        network.set_compute_dtype(model, dt)
+        with torch.no_grad():
+            got = model(x.to(dev)).float().cpu()
+        mask = got.argmax(1)
+        flips = (mask != ref_mask)
+        dices = []
+        for c in range(args.classes):
+            p = (mask == c).double()
+            g = (ref_mask == c).double()
+            tp = (p * g).sum()
+            fn = ((1 - p) * g).sum()
+            fp = (p * (1 - g)).sum()
+            dices.append(float((tp + 1e-7) / (tp + 0.5 * fn + 0.5 * fp + 1e-7)))   # loss.py:32-48, alpha=beta=0.5
+        out[name] = {"dice_vs_cpu_ref": dices, "argmax_flips": int(flips.sum()), "voxels": int(flips.numel()),
+                     "flips_beyond_margin": int((flips & (margin > band)).sum()), "margin_band": band,
+                     "max_abs_logit_err": float((got - ref).abs().max())}
+        if dt == dtype == torch.float32:
+            break
+    network.set_compute_dtype(model, dtype)
+    model.train(was_training)
+    return out
 
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if world == 0 and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    world = max(world, 1)
+    if args.gpus != world:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d (launch N ranks, or drop the launcher and let bench.py "
+              "start them)" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    one_device = os.environ.get("RU3D_ONE_DEVICE") == "1"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # rehearsal knobs (one-GPU box): RU3D_DIST_BACKEND=gloo RU3D_ONE_DEVICE=1 runs every rank on cuda:0 over gloo, so
-        # the multi-rank code path (GradSync buckets, fused Adam on aliased gradients) is exercised without RCCL
-        backend = os.environ.get("RU3D_DIST_BACKEND", "nccl")
-        if os.environ.get("RU3D_ONE_DEVICE") == "1":
+        # torch.distributed = rendezvous + control plane (store, barrier, the max over ranks of the timing) on gloo;
+        # the gradient exchange itself is RCCL through the C ABI (parallel.RcclComm) on a side HIP stream.
+        # rehearsal knob (one-GPU box): RU3D_ONE_DEVICE=1 runs every rank on cuda:0 and exchanges gradients over gloo
+        # (RCCL refuses two ranks on one device), so bucketing / aliasing / fused Adam run exactly as on N GPUs
+        if one_device:
             local = 0
         torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if world > 1 else 0)
@@ -103,40 +229,60 @@ def main():
     import loss as loss_mod
     import network
 
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    dims = tuple(args.patch) if len(args.patch) == 3 else (args.patch[0],) * 3
     torch.manual_seed(0)
     model = network.ResUnet3D(args.pools, args.features, 1, args.classes).to(dev)
     network.set_compute_dtype(model, dtype)
+    if args.checkpoint:
+        network.set_checkpointing(model, True)
     model.train(not args.eval_mode)
     sync = None
+    transport = None
     if world > 1:
         from parallel import GradSync, broadcast_parameters
         broadcast_parameters(model)
-        sync = GradSync(model)
+        transport = os.environ.get("RU3D_COMM", "torch" if one_device else "rccl")
+        gd = torch.bfloat16 if (args.grad_transport == "bf16" and transport == "rccl") else torch.float32
+        sync = GradSync(model, transport=transport, grad_dtype=gd)
     if args.optimizer == "fused":
         import optim
         opt = optim.Adam(model.parameters(), lr=1e-4)      # same update rule, one launch for the whole model
     else:
         opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    scaler = None
+    if dtype == torch.float16:
+        import optim as optim_mod
+        scaler = optim_mod.LossScaler()
     wv = [1, 10, 20][:args.classes] if args.classes <= 3 else None
     criterion = loss_mod.HybirdLoss(weight_v=wv)
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    shape = (args.batch, 1, args.patch, args.patch, args.patch)
+    shape = (args.batch, 1) + dims
     x = torch.randn(shape, generator=g, device=dev).clamp_(-2.34, 2.64)
-    y = torch.randint(0, args.classes, (args.batch,) + shape[2:], generator=g, device=dev)
+    y = torch.randint(0, args.classes, (args.batch,) + dims, generator=g, device=dev)
 
-    def step():
-        logits = model(x)
-        loss = criterion(logits, y)
-        opt.zero_grad()
-        if sync is not None:
-            sync.begin_step()
-        loss.backward()
-        if sync is not None:
-            sync.finish_step()
-        opt.step()
-        return loss
+    def make_step(optimizer):
+        def step():
+            logits = model(x)
+            loss = criterion(logits, y)
+            optimizer.zero_grad()
+            if sync is not None:
+                sync.begin_step()
+            if scaler is not None:
+                scaler.scale(loss).backward()
+            else:
+                loss.backward()
+            if sync is not None:
+                sync.finish_step()
+            if scaler is not None:
+                scaler.step(optimizer)
+            else:
+                optimizer.step()
+            return loss
+        return step
+
+    step = make_step(opt)
 
     def fence():
         if world > 1:
@@ -151,10 +297,11 @@ def main():
     gc.collect()
     gc.freeze()
     probe = None
-    if not args.no_probe:
-        probe = ops.Probe(cin=args.features, cout=args.features, k=3, stride=1,
-                          extent=(args.patch, args.patch, args.patch))
+    if not args.no_probe and dtype != torch.float32:
+        probe = ops.Probe(cin=args.features, cout=args.features, k=3, stride=1, extent=dims)
         ops.set_probe(probe)
+    torch.cuda.reset_peak_memory_stats(dev)
+    fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -162,30 +309,46 @@ def main():
     dt = time.perf_counter() - t0
     ops.set_probe(None)
     loss_value = float(loss.item())
+    peak_mem = torch.cuda.max_memory_allocated(dev)
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    vox_per_step = args.batch * args.patch ** 3
+    vox_per_step = args.batch * dims[0] * dims[1] * dims[2]
     total = vox_per_step * args.steps * world / dt
+    cube = dims[0] == dims[1] == dims[2]
+    shape_txt = ("%d^3" % dims[0]) if cube else "%dx%dx%d" % dims
     out = {
-        "metric": "train voxels/sec (128^3 patch, bs=2 per GPU), whole job",
+        "metric": "train voxels/sec (%s patch, bs=%d per GPU), whole job" % (shape_txt, args.batch),
         "value": total, "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "per_gpu": total / world, "final_loss": loss_value,
-        "config": {"workload": "config2: ResUnet3D(num_pool=%d, num_features=%d, in=1, out=%d) train step "
-                               "(fwd+HybirdLoss+bwd+Adam), %dx1x%d^3 per GPU, dropout %s" %
-                               (args.pools, args.features, args.classes, args.batch, args.patch,
-                                "off" if args.eval_mode else "on"),
-                   "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+        "per_gpu": total / world, "final_loss": loss_value, "peak_mem_gib": peak_mem / 2 ** 30,
+        "config": {"workload": "ResUnet3D(num_pool=%d, num_features=%d, in=1, out=%d) train step "
+                               "(fwd+HybirdLoss+bwd+Adam), %dx1x%s per GPU, dropout %s%s" %
+                               (args.pools, args.features, args.classes, args.batch, shape_txt,
+                                "off" if args.eval_mode else "on", ", activation checkpointing" if args.checkpoint
+                                else ""),
+                   "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                   "optimizer": "optim.Adam (fused multi-tensor)" if args.optimizer == "fused" else "torch.optim.Adam"},
     }
+    if world > 1:
+        out["config"]["grad_exchange"] = ("RCCL all-reduce via ru3d_comm_allreduce, side HIP stream, 64 MiB buckets, "
+                                          "%s transport" % args.grad_transport) if transport == "rccl" else \
+            "torch.distributed (%s)" % dist.get_backend()
+    elem = 4 if dtype == torch.float32 else 2
+    sflops, sbytes = alg_work(args.pools, args.features, args.classes, args.batch, dims, elem)
+    t_step = dt / args.steps
+    peak_f = MFMA_BF16_PEAK if elem == 2 else 157.3e12
+    out["roofline_step"] = {"alg_flops": sflops, "alg_bytes": sbytes, "achieved_tflops": sflops / t_step / 1e12,
+                            "frac_mfma": sflops / t_step / peak_f, "achieved_gbps": sbytes / t_step / 1e9,
+                            "frac_hbm": sbytes / t_step / HBM_PEAK, "peak_tflops": peak_f / 1e12,
+                            "bound_ms": 1e3 * max(sflops / peak_f, sbytes / HBM_PEAK)}
     if probe is not None:
         n_launch, mean_ms = probe.result()
-        elem = 2 if dtype == torch.bfloat16 else 4
-        v = args.batch * args.patch ** 3
+        v = vox_per_step
         c = args.features
         alg_bytes = (v * c + v * c + 27 * c * c) * elem          # |in| + |out| + |W|
         alg_flops = 2.0 * v * 27 * c * c
@@ -194,33 +357,53 @@ def main():
             hbm = alg_bytes / t
             mf = alg_flops / t
             # the 32->32 3x3x3 conv has AI = 432 FLOP/B against a ridge of 312 (2.5 PF / 8 TB/s): at the spec peaks the
-            # MFMA bound (93 us) is the longer of the two minimum times (HBM: 67 us), and the measured HBM traffic equals
-            # the algorithmic bytes, so the launch is priced against the dense bf16 MFMA peak; the HBM view rides along
-            # HBM bytes per launch of this kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
-            # FETCH_SIZE / WRITE_SIZE in separate runs of tools/kbench.py, gfx950 correction applied by
-            # tools/pmc_traffic.py); null when no such measurement exists for this shape.
+            # MFMA bound (93 us) is the longer of the two minimum times (HBM: 67 us), so the launch is priced against
+            # the dense bf16 MFMA peak; the HBM view rides along.  `traffic` = HBM bytes per launch of this kernel from
+            # the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+            # tools/kbench.py, gfx950 correction applied by tools/pmc_traffic.py); null when there is none for the shape.
             traffic = None
-            key = "conv3d k3 s1 %d->%d on %dx%d^3" % (c, c, args.batch, args.patch)
+            key = "conv3d k3 s1 %d->%d on %dx%d^3" % (c, c, args.batch, dims[0])
             try:
                 pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_traffic.json"))
-                if pmc and dtype == torch.bfloat16:
+                if pmc and elem == 2 and cube:
                     traffic = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))[key]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
-            out["roofline"] = {"kernel": "conv3d k3 s1 %d->%d on %dx%d^3 (fwd + dgrad launches)" %
-                                         (c, c, args.batch, args.patch),
+            out["roofline"] = {"kernel": "conv3d k3 s1 %d->%d on %dx%s (fwd + dgrad launches)" %
+                                         (c, c, args.batch, shape_txt),
                                "bound": "mfma", "achieved": mf / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                                "frac": mf / MFMA_BF16_PEAK, "traffic": traffic, "launches": n_launch,
                                "avg_ms": mean_ms, "alg_bytes": alg_bytes, "alg_flops": alg_flops,
                                "hbm_gbps": hbm / 1e9, "hbm_frac": hbm / HBM_PEAK}
+    if world == 1 and args.optimizer == "fused" and not args.no_torch_adam:
+        # the caller-owned optimizer of the reference scripts (nb_train_iia.py:18) on the same model
+        topt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        tstep = make_step(topt)
+        for _ in range(2):
+            tstep()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            tstep()
+        fence()
+        out["ms_per_step_torch_adam"] = 1e3 * (time.perf_counter() - t1) / args.steps
+        del topt
+    if rank == 0 and world == 1 and not args.no_parity:
+        try:
+            out["parity"] = parity_report(args, model, dims, dev, dtype)
+        except Exception as e:  # pragma: no cover
+            out["parity"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, dims)
         except Exception as e:  # pragma: no cover
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        if sync is not None:
+            torch.cuda.synchronize()
+            sync.remove()
         dist.destroy_process_group()
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RU3D_VERSION 100
+#define RU3D_VERSION 200
 
 /* storage dtypes of activations / packed weights (accumulation is always fp32) */
 enum { RU3D_F32 = 0, RU3D_BF16 = 1 };
@@ -216,6 +216,25 @@ typedef struct ru3d_adam_tensor {
 int ru3d_adam_multi(const ru3d_adam_tensor* tensors, const int32_t* block_map, int nblocks, int chunk_elems,
                     float lr, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
                     float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------ gradient exchange (RCCL) */
+/* Data-parallel training: one process per GPU, one exchange per step - the mean of the parameter gradients over
+ * ranks.  The reference has no distributed code (it pins one device, nb_train_iia.py:17); these entry points are
+ * the build's own contract.  RCCL is resolved with dlopen at first use.
+ *   rank 0:      ru3d_comm_unique_id(blob)      -> the host ships the 128-byte blob to every rank (any channel)
+ *   every rank:  ru3d_comm_init(&comm, blob, world, rank, device)     (collective: all ranks must call it)
+ *   per bucket:  ru3d_comm_allreduce(comm, buf, count, dtype, average, stream)   in place, enqueue-only
+ *   at exit:     ru3d_comm_destroy(comm)
+ * The communicator handle is the only state the library keeps, and it is owned by the caller. */
+#define RU3D_COMM_ID_BYTES 128
+int ru3d_comm_unique_id(void* id_out);
+int ru3d_comm_init(void** comm_out, const void* unique_id, int world, int rank, int device);
+/* buf: device buffer of `count` elements (RU3D_F32 or RU3D_BF16); average != 0 divides the sum by the world size. */
+int ru3d_comm_allreduce(void* comm, void* buf, int64_t count, int dtype, int average, void* stream);
+int ru3d_comm_destroy(void* comm);
+/* dst[i] = (dst_dtype)(src[i] * scale) on flat 16-byte-aligned device arrays, f32 <-> bf16: the copy-in / copy-out
+ * of a bf16 gradient bucket (half the bytes over xGMI). */
+int ru3d_flat_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t count, float scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(N.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert N.lib.ru3d_version() == 100
+    assert N.lib.ru3d_version() == 200
     # pure host-side queries work without a device
     assert N.lib.ru3d_loss_state_bytes(3) > 0
     assert N.lib.ru3d_packed_weight_bytes(32, 32, 3, 1, N.ROLE_CONV_FWD, N.BF16) > 0
@@ -256,3 +256,42 @@ def test_predict_per_patch_refuses_cpu_model_and_odd_patch():
     model = network.ResUnet3D(1, 4, 1, 2)
     with pytest.raises(N.Ru3dError):
         I.predict_per_patch(np.zeros((8, 8, 8, 1), np.float32), model, 2, (8, 8, 8), 2, False)
+
+
+# --------------------------------------------------------------------------- round 2: launcher / device plumbing
+def test_bench_refuses_gpus_that_disagree_with_the_launcher():
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 2 and b"WORLD_SIZE=3" in p.stderr
+
+
+def test_bench_algorithmic_work_matches_survey_table():
+    """ALG_FLOPS / ALG_BYTES per step for the four configurations."""
+    import bench
+    for cfg, flops, nbytes in (((2, 8, 2, 1, (32,) * 3, 4), 3.49e9, 75e6),
+                               ((4, 32, 3, 2, (128,) * 3, 2), 9.004e12, 19.98e9),
+                               ((4, 30, 3, 2, (160, 160, 80), 2), 7.730e12, 18.28e9),
+                               ((5, 64, 3, 1, (192,) * 3, 2), 63.36e12, 76.53e9)):
+        f, b = bench.alg_work(*cfg)
+        assert abs(f - flops) / flops < 2e-3 and abs(b - nbytes) / nbytes < 3e-3, (cfg, f, b)
+
+
+def test_stream_follows_the_operands_device(monkeypatch):
+    """the stream handed to the C ABI is the current stream of the operands' device, not of the
+    thread's current device."""
+    import types
+    seen = []
+
+    def fake_current_stream(device=None):
+        seen.append(device)
+        return types.SimpleNamespace(cuda_stream=1234)
+
+    monkeypatch.setattr(torch.cuda, "current_stream", fake_current_stream)
+    N.note_device(torch.device("cuda", 1))
+    assert N.stream().value == 1234 and seen[-1] == torch.device("cuda", 1)
+    N.note_device(torch.device("cuda", 0))
+    N.stream()
+    assert seen[-1] == torch.device("cuda", 0)
