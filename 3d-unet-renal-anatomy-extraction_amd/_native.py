@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("RU3D_LIB", os.path.join(_HERE, "libru3d.so"))
 
 F32, BF16 = 0, 1
 LABEL_I64, LABEL_U8 = 0, 1
-ROLE_CONV_FWD, ROLE_CONV_DGRAD, ROLE_CONVT_FWD, ROLE_CONVT_DGRAD = 0, 1, 2, 3
+ROLE_CONV_FWD, ROLE_CONV_DGRAD, ROLE_CONVT_FWD, ROLE_CONVT_DGRAD, ROLE_BIAS = 0, 1, 2, 3, 4
 LOSS_HYBIRD, LOSS_DICELOSS, LOSS_FOCAL, LOSS_DICE = 0, 1, 2, 3
 MAX_CLASSES = 8
 
@@ -29,10 +29,11 @@ class Tensor(ctypes.Structure):
 class PackItem(ctypes.Structure):
     """struct ru3d_pack_item"""
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("cout", ctypes.c_int32), ("cin", ctypes.c_int32),
-                ("k", ctypes.c_int32), ("stride", ctypes.c_int32), ("role", ctypes.c_int32)]
+                ("k", ctypes.c_int32), ("stride", ctypes.c_int32), ("role", ctypes.c_int32),
+                ("cout_seg", ctypes.c_int32), ("cin_seg", ctypes.c_int32)]
 
 
-PACK_MAX = 8
+PACK_MAX = 12
 _P = ctypes.POINTER(Tensor)
 _vp, _i, _i64, _f, _sz, _u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t,
                                 ctypes.c_uint64)
@@ -44,6 +45,7 @@ SIGNATURES = {
     "ru3d_packed_weight_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "ru3d_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ru3d_pack_weights": (_i, [ctypes.POINTER(PackItem), _i, _i, _vp]),
+    "ru3d_unpad_weight_grad": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ru3d_conv3d_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),
     "ru3d_conv3d_fwd": (_i, [_P, _vp, _vp, _P, _P, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ru3d_conv3d_fwd_in_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),

@@ -44,28 +44,53 @@ _PACK_CACHE = {}
 WEIGHTS_EPOCH = [0]   # bumped by optim.Adam.step (its kernel writes the parameters behind torch's back)
 
 
+def cpad(c):
+    """Channel count of the padded activation that carries `c` real channels on the MFMA kernels."""
+    return (c + 31) // 32 * 32
+
+
+def padded_dim(real, seg):
+    return (real // seg) * cpad(seg) if seg else real
+
+
+def seg_of(real, have, nseg=1):
+    """Segment size with which a tensor of `have` channels carries a weight dimension of `real` channels as `nseg`
+    zero-padded segments (the decoder's concat input is two: 30 | 30 -> 32 | 32); checks that it does."""
+    if real % nseg or nseg * cpad(real // nseg) != have:
+        raise N.Ru3dError("ru3d: a tensor with %d channels is not the padded form of %d channels in %d segment(s)"
+                          % (have, real, nseg))
+    return real // nseg
+
+
 def pack_weights(specs, dtype):
-    """specs: list of (weight, role, stride) -> list of packed tensors, produced by ONE kernel launch per
-    RU3D_PACK_MAX weights (the packs share one allocation).  The size/offset plan and the ctypes item arrays of a
-    spec list are built once and reused while the parameters stay where they are (same data pointers)."""
+    """specs: list of (tensor, role, stride[, cout_seg, cin_seg]) -> list of packed tensors, produced by ONE kernel
+    launch per RU3D_PACK_MAX items (the packs share one allocation).  role ROLE_BIAS pads a bias vector
+    ([cout] -> fp32 [padded cout]).  The size/offset plan and the ctypes item arrays of a spec list are built once
+    and reused while the parameters stay where they are (same data pointers)."""
     code = N.dtype_code(dtype)
-    key = (code,) + tuple((w.data_ptr(), w.shape, role, stride) for w, role, stride in specs)
+    specs = [sp if len(sp) == 5 else (sp[0], sp[1], sp[2], 0, 0) for sp in specs]
+    key = (code,) + tuple((w.data_ptr(), w.shape, role, stride, cs, ci) for w, role, stride, cs, ci in specs)
     plan = _PACK_PLANS.get(key)
     if plan is None:
         metas, sizes = [], []
-        for w, role, stride in specs:
+        for w, role, stride, cout_seg, cin_seg in specs:
             N.require_device(w, "weight")
             if w.dtype != torch.float32 or not w.is_contiguous():
                 raise N.Ru3dError("ru3d: weights must be contiguous float32 parameters")
-            k = w.shape[2]
-            if role in (N.ROLE_CONVT_FWD, N.ROLE_CONVT_DGRAD):
-                cin, cout, stride = w.shape[0], w.shape[1], 2
+            if role == N.ROLE_BIAS:
+                cout, cin, k, stride = w.shape[0], 1, 1, 1
+                nbytes = 4 * padded_dim(cout, cout_seg)
             else:
-                cout, cin = w.shape[0], w.shape[1]
-            nbytes = N.lib.ru3d_packed_weight_bytes(cout, cin, k, stride, role, code)
+                k = w.shape[2]
+                if role in (N.ROLE_CONVT_FWD, N.ROLE_CONVT_DGRAD):
+                    cin, cout, stride = w.shape[0], w.shape[1], 2
+                else:
+                    cout, cin = w.shape[0], w.shape[1]
+                nbytes = N.lib.ru3d_packed_weight_bytes(padded_dim(cout, cout_seg), padded_dim(cin, cin_seg), k, stride,
+                                                        role, code)
             if nbytes == 0:
                 raise N.Ru3dError("ru3d: cannot pack weight of shape %s" % (tuple(w.shape),))
-            metas.append((w.data_ptr(), cout, cin, k, stride, role))
+            metas.append((w.data_ptr(), cout, cin, k, stride, role, cout_seg, cin_seg))
             sizes.append((nbytes + 255) // 256 * 256)
         offs, off = [], 0
         for sz in sizes:
@@ -75,8 +100,8 @@ def pack_weights(specs, dtype):
         for i0 in range(0, len(metas), N.PACK_MAX):
             chunk = metas[i0:i0 + N.PACK_MAX]
             items = (N.PackItem * len(chunk))()
-            for j, (src, cout, cin, k, stride, role) in enumerate(chunk):
-                items[j] = N.PackItem(src, 0, cout, cin, k, stride, role)
+            for j, (src, cout, cin, k, stride, role, cout_seg, cin_seg) in enumerate(chunk):
+                items[j] = N.PackItem(src, 0, cout, cin, k, stride, role, cout_seg, cin_seg)
             chunks.append((i0, items))
         plan = (sizes, offs, off, chunks)
         if len(_PACK_PLANS) > 4096:
@@ -88,13 +113,13 @@ def pack_weights(specs, dtype):
     # fused optimizer bumps because it updates parameters through raw pointers.
     dev0 = specs[0][0].device
     N.note_device(dev0)
-    ver = tuple(w._version for w, _, _ in specs) + (WEIGHTS_EPOCH[0], torch.cuda.current_stream(dev0).cuda_stream)
+    ver = tuple(sp[0]._version for sp in specs) + (WEIGHTS_EPOCH[0], torch.cuda.current_stream(dev0).cuda_stream)
     use_cache = not torch.is_grad_enabled()      # inference only: training repacks after every optimizer step anyway
     hit = _PACK_CACHE.get(key) if use_cache else None
     # the entry belongs to these very tensor objects (a freed parameter's address and version can both recur)
-    if hit is not None and hit[0] == ver and all(r() is w for r, (w, _, _) in zip(hit[2], specs)):
+    if hit is not None and hit[0] == ver and all(r() is sp[0] for r, sp in zip(hit[2], specs)):
         return hit[1]
-    buf = torch.empty(total, dtype=torch.uint8, device=specs[0][0].device)
+    buf = torch.empty(total, dtype=torch.uint8, device=dev0)
     base = buf.data_ptr()
     outs = [buf[o:o + sz] for o, sz in zip(offs, sizes)]
     st = stream()
@@ -105,8 +130,20 @@ def pack_weights(specs, dtype):
     if use_cache:
         if len(_PACK_CACHE) > 4096:
             _PACK_CACHE.clear()
-        _PACK_CACHE[key] = (ver, outs, [weakref.ref(w) for w, _, _ in specs])
+        _PACK_CACHE[key] = (ver, outs, [weakref.ref(sp[0]) for sp in specs])
     return outs
+
+
+def unpad_wgrad(dw_p, cout, cin, cout_seg, cin_seg):
+    """Weight gradient computed on padded channels ([cout_p, cin_p, k,k,k]) -> the parameter's shape."""
+    if not cout_seg and not cin_seg:
+        return dw_p
+    k = dw_p.shape[2]
+    out = torch.empty((cout, cin, k, k, k), dtype=torch.float32, device=dw_p.device)
+    N.note_device(dw_p.device)
+    check(N.lib.ru3d_unpad_weight_grad(ptr(dw_p), ptr(out), cout, cin, k * k * k, cout_seg, cin_seg, stream()),
+          "unpad_weight_grad")
+    return out
 
 
 def _bias(b):
@@ -451,20 +488,35 @@ def _join(device, *outs):
 
 
 # --------------------------------------------------------------------------- autograd: plain conv (stem / head / skip)
+def _f32_view(pack, count):
+    """fp32 view of a ROLE_BIAS pack (the packs are 256-byte aligned slices of one uint8 allocation)."""
+    return pack[:4 * count].view(torch.float32)
+
+
 class ConvFn(torch.autograd.Function):
-    """nn.Conv3d(k in {1,3}, stride in {1,2}, padding=k//2) with bias: reference network.py:541-547 (stem, head)."""
+    """nn.Conv3d(k in {1,3}, stride in {1,2}, padding=k//2) with bias: reference network.py:541-547 (stem, head).
+    pad_in / pad_out: the input / output activation carries its channels zero-padded to a multiple of 32."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, storage_dtype, out_dtype):
+    def forward(ctx, x, weight, bias, stride, storage_dtype, out_dtype, pad_in=False, pad_out=False):
         xin = as_input(x, storage_dtype)
         k = weight.shape[2]
-        specs = [(weight, N.ROLE_CONV_FWD, stride)]
+        cout, cin = weight.shape[0], weight.shape[1]
+        cin_seg = seg_of(cin, xin.shape[1]) if pad_in else 0
+        cout_seg = cout if pad_out else 0
+        if not pad_in and xin.shape[1] != cin:
+            raise N.Ru3dError("conv: input has %d channels, weight expects %d" % (xin.shape[1], cin))
+        cout_p = padded_dim(cout, cout_seg)
+        specs = [(weight, N.ROLE_CONV_FWD, stride, cout_seg, cin_seg)]
         if ctx.needs_input_grad[0]:
-            specs.append((weight, N.ROLE_CONV_DGRAD, stride))
+            specs.append((weight, N.ROLE_CONV_DGRAD, stride, cout_seg, cin_seg))
+        if cout_seg and bias is not None:
+            specs.append((bias, N.ROLE_BIAS, 1, cout_seg, 0))
         packs = pack_weights(specs, storage_dtype)
-        y = conv_fwd(xin, packs[0], bias, weight.shape[0], k, stride, out_dtype=out_dtype)
-        ctx.save_for_backward(xin, packs[1] if len(packs) > 1 else None)
-        ctx.cout = weight.shape[0]
+        b = _f32_view(packs[-1], cout_p) if (cout_seg and bias is not None) else bias
+        y = conv_fwd(xin, packs[0], b, cout_p, k, stride, out_dtype=out_dtype)
+        ctx.save_for_backward(xin, packs[1] if ctx.needs_input_grad[0] else None)
+        ctx.dims = (cout, cin, cout_seg, cin_seg)
         ctx.stride, ctx.k, ctx.has_bias = stride, k, bias is not None
         ctx.storage_dtype = storage_dtype
         ctx.in_dtype = x.dtype
@@ -474,19 +526,20 @@ class ConvFn(torch.autograd.Function):
     def backward(ctx, gy):
         xin, pwd = ctx.saved_tensors
         sd = ctx.storage_dtype
+        cout, cin, cout_seg, cin_seg = ctx.dims
         gy = as_grad(gy, sd)
         gx = gw = gb = None
         with _OnSide(gy.device):
             if ctx.needs_input_grad[1]:
-                gw = conv_wgrad(xin, gy, ctx.k, ctx.stride)
+                gw = unpad_wgrad(conv_wgrad(xin, gy, ctx.k, ctx.stride), cout, cin, cout_seg, cin_seg)
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = channel_sum(gy)
+                gb = channel_sum(gy)[:cout]
         if ctx.needs_input_grad[0]:
             gx = conv_dgrad(gy, pwd, tuple(xin.shape), ctx.k, ctx.stride)
             if gx.dtype != ctx.in_dtype:
                 gx = gx.to(ctx.in_dtype)
         _join(gy.device, gw, gb)
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------- autograd: ResBlock
@@ -494,64 +547,93 @@ class ResBlockFn(torch.autograd.Function):
     """reference network.py:405-416:
         skip = skip_conv(x) if (in != out or stride != 1) else x
         x = conv1(x); x = dropout(x); x = lrelu(IN(x)); x = conv2(x); return lrelu(IN(x) + skip)
+    pad: x and the result carry their channels zero-padded to multiples of 32 (F = 30 widths on the MFMA kernels).
+    checkpoint: only the block's input, output and the InstanceNorm statistics are kept for backward; the three
+    interior tensors (conv1 output, its activation, conv2 output) are recomputed there by the same kernels, so the
+    gradients are the same bits (BASELINE config 5: activation checkpointing).
     """
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, ws, bs, stride, drop_scale):
+    def forward(ctx, x, w1, b1, w2, b2, ws, bs, stride, drop_scale, pad=0, checkpoint=False):
         sd = x.dtype
         x = N.to_ndhwc(x)
-        cout = w1.shape[0]
+        cout, cin = w1.shape[0], w1.shape[1]
+        cin_seg = seg_of(cin, x.shape[1], int(pad)) if pad else 0      # pad = number of input segments
+        cout_seg = cout if pad else 0
+        if not pad and x.shape[1] != cin:
+            raise N.Ru3dError("ResBlock: input has %d channels, conv1 expects %d" % (x.shape[1], cin))
+        cout_p = padded_dim(cout, cout_seg)
         # every packed form this block needs (forward now, input gradients later) in one launch
         train = any(ctx.needs_input_grad)
         need_gx = ctx.needs_input_grad[0]
-        specs = [(w1, N.ROLE_CONV_FWD, stride), (w2, N.ROLE_CONV_FWD, 1)]
+        specs = [(w1, N.ROLE_CONV_FWD, stride, cout_seg, cin_seg), (w2, N.ROLE_CONV_FWD, 1, cout_seg, cout_seg)]
         if ws is not None:
-            specs.append((ws, N.ROLE_CONV_FWD, stride))
+            specs.append((ws, N.ROLE_CONV_FWD, stride, cout_seg, cin_seg))
         nfwd = len(specs)
         if train:
-            specs.append((w2, N.ROLE_CONV_DGRAD, 1))
+            specs.append((w2, N.ROLE_CONV_DGRAD, 1, cout_seg, cout_seg))
             if need_gx:
-                specs.append((w1, N.ROLE_CONV_DGRAD, stride))
+                specs.append((w1, N.ROLE_CONV_DGRAD, stride, cout_seg, cin_seg))
                 if ws is not None:
-                    specs.append((ws, N.ROLE_CONV_DGRAD, stride))
+                    specs.append((ws, N.ROLE_CONV_DGRAD, stride, cout_seg, cin_seg))
+        nw = len(specs)
+        if cout_seg:
+            specs += [(b, N.ROLE_BIAS, 1, cout_seg, 0) for b in (b1, b2, bs) if b is not None]
         packs = pack_weights(specs, sd)
+        if cout_seg:
+            it = iter(packs[nw:])
+            b1, b2, bs = [(_f32_view(next(it), cout_p) if b is not None else None) for b in (b1, b2, bs)]
         pw1, pw2 = packs[0], packs[1]
-        y1, mean1, scale1 = conv_fwd_in(x, pw1, b1, cout, 3, stride, drop_scale)
+        y1, mean1, scale1 = conv_fwd_in(x, pw1, b1, cout_p, 3, stride, drop_scale)
         a1 = in_lrelu_fwd(y1, mean1, scale1)
-        y2, mean2, scale2 = conv_fwd_in(a1, pw2, b2, cout, 3, 1)
+        y2, mean2, scale2 = conv_fwd_in(a1, pw2, b2, cout_p, 3, 1)
         if ws is not None:
-            skip = conv_fwd(x, packs[2], bs, cout, 1, stride)
+            skip = conv_fwd(x, packs[2], bs, cout_p, 1, stride)
         else:
             skip = x
         z = in_lrelu_fwd(y2, mean2, scale2, res=skip)
-        bwd = packs[nfwd:] + [None] * 3
-        ctx.save_for_backward(x, y1, a1, y2, z, mean1, scale1, mean2, scale2, bwd[0], bwd[1], bwd[2])
-        ctx.shapes = (tuple(w1.shape), tuple(w2.shape))
+        bwd = packs[nfwd:nw] + [None] * 3
+        if checkpoint and train:
+            ctx.save_for_backward(x, None, None, None, z, mean1, scale1, mean2, scale2, bwd[0], bwd[1], bwd[2],
+                                  pw1, pw2, b1, b2)
+        else:
+            ctx.save_for_backward(x, y1, a1, y2, z, mean1, scale1, mean2, scale2, bwd[0], bwd[1], bwd[2],
+                                  None, None, None, None)
+        ctx.dims = (cout, cin, cout_seg, cin_seg)
         ctx.stride = stride
         ctx.has_skip_conv = ws is not None
         return z
 
     @staticmethod
     def backward(ctx, gz):
-        x, y1, a1, y2, z, mean1, scale1, mean2, scale2, pw2d, pw1d, pwsd = ctx.saved_tensors
+        (x, y1, a1, y2, z, mean1, scale1, mean2, scale2, pw2d, pw1d, pwsd, pw1, pw2, b1, b2) = ctx.saved_tensors
+        cout, cin, cout_seg, cin_seg = ctx.dims
+        cout_p = padded_dim(cout, cout_seg)
         sd = x.dtype
         dev = x.device
         stride = ctx.stride
         gz = as_grad(gz, sd)
+        if y1 is None:      # checkpointed: the same kernels on the same inputs give the same bits
+            y1 = conv_fwd(x, pw1, b1, cout_p, 3, stride)
+            a1 = in_lrelu_fwd(y1, mean1, scale1)
+            y2 = conv_fwd(a1, pw2, b2, cout_p, 3, 1)
         # lrelu(IN(y2) + skip): dy2 and the pre-activation gradient (= d/dskip)
         # sum(gpre) - the skip conv's bias gradient - comes out of the same reduction
         dy2, gpre, gbs_sum = in_lrelu_bwd(gz, z, y2, mean2, scale2, want_gpre=True, want_gpre_sum=True)
+        del y2
         gws = gbs = None
         with _OnSide(dev):
-            gw2 = conv_wgrad(a1, dy2, 3, 1)
+            gw2 = unpad_wgrad(conv_wgrad(a1, dy2, 3, 1), cout, cout, cout_seg, cout_seg)
             if ctx.has_skip_conv:
-                gws = conv_wgrad(x, gpre, 1, stride)
-                gbs = gbs_sum
+                gws = unpad_wgrad(conv_wgrad(x, gpre, 1, stride), cout, cin, cout_seg, cin_seg)
+                gbs = gbs_sum[:cout]
         gb2 = None   # a bias that feeds InstanceNorm has an identically zero gradient: reported as "no gradient"
         da1 = conv_dgrad(dy2, pw2d, tuple(a1.shape), 3, 1)
+        del dy2
         dy1, _ = in_lrelu_bwd(da1, a1, y1, mean1, scale1)
+        del da1, a1, y1
         with _OnSide(dev):
-            gw1 = conv_wgrad(x, dy1, 3, stride)
+            gw1 = unpad_wgrad(conv_wgrad(x, dy1, 3, stride), cout, cin, cout_seg, cin_seg)
         gb1 = None
         gx = None
         need_gx = ctx.needs_input_grad[0]
@@ -562,7 +644,7 @@ class ResBlockFn(torch.autograd.Function):
         elif need_gx:
             gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gpre)
         _join(dev, gw1, gw2, gws, gbs)
-        return gx, gw1, gb1, gw2, gb2, gws, gbs, None, None
+        return gx, gw1, gb1, gw2, gb2, gws, gbs, None, None, None, None
 
 
 # --------------------------------------------------------------------------- autograd: ConvTrans3D (+ concat)
@@ -570,19 +652,28 @@ class UpFn(torch.autograd.Function):
     """reference network.py:311-317 (+ :346-350 when `skip` is given):
         u = lrelu(IN(pad_far(convT_k3s2p1(x))));  return cat((u, skip), dim=1)
     The concat is written in place: the IN+LeakyReLU kernel stores into the first channels of the
-    output buffer, a channel-slice copy fills the rest.
+    output buffer, a channel-slice copy fills the rest.  pad: channel-padded activations (see ResBlockFn); the
+    concat is then [u padded | skip padded].
     """
 
     @staticmethod
-    def forward(ctx, x, wt, bt, skip):
+    def forward(ctx, x, wt, bt, skip, pad=False):
         sd = x.dtype
         x = N.to_ndhwc(x)
-        cout = wt.shape[1]
-        specs = [(wt, N.ROLE_CONVT_FWD, 2)]
+        cin, cout = wt.shape[0], wt.shape[1]
+        cin_seg = seg_of(cin, x.shape[1]) if pad else 0
+        cout_seg = cout if pad else 0
+        if not pad and x.shape[1] != cin:
+            raise N.Ru3dError("ConvTrans3D: input has %d channels, weight expects %d" % (x.shape[1], cin))
+        cout_p = padded_dim(cout, cout_seg)
+        specs = [(wt, N.ROLE_CONVT_FWD, 2, cout_seg, cin_seg)]
         if ctx.needs_input_grad[0]:
-            specs.append((wt, N.ROLE_CONVT_DGRAD, 2))
+            specs.append((wt, N.ROLE_CONVT_DGRAD, 2, cout_seg, cin_seg))
+        if cout_seg and bt is not None:
+            specs.append((bt, N.ROLE_BIAS, 1, cout_seg, 0))
         packs = pack_weights(specs, sd)
-        y = convt_fwd(x, packs[0], bt, cout)
+        btp = _f32_view(packs[-1], cout_p) if (cout_seg and bt is not None) else bt
+        y = convt_fwd(x, packs[0], btp, cout_p)
         mean, scale = in_stats(y)
         n, _, d, h, w = y.shape
         if skip is not None:
@@ -590,34 +681,36 @@ class UpFn(torch.autograd.Function):
             cs = skip.shape[1]
             if tuple(skip.shape[2:]) != (d, h, w) or skip.shape[0] != n:
                 raise N.Ru3dError("UpConcat: skip %s does not match up-sampled %s" % (tuple(skip.shape), tuple(y.shape)))
-            buf = N.new_act(n, cout + cs, d, h, w, sd, x.device)
-            u = buf[:, :cout]
+            buf = N.new_act(n, cout_p + cs, d, h, w, sd, x.device)
+            u = buf[:, :cout_p]
             in_lrelu_fwd(y, mean, scale, out=u)
-            copy_channels(skip, buf[:, cout:])
+            copy_channels(skip, buf[:, cout_p:])
             out = buf
         else:
             u = in_lrelu_fwd(y, mean, scale)
             out = u
-        ctx.save_for_backward(x, y, out, mean, scale, packs[1] if len(packs) > 1 else None)
-        ctx.cout = cout
+        ctx.save_for_backward(x, y, out, mean, scale, packs[1] if ctx.needs_input_grad[0] else None)
+        ctx.dims = (cout, cin, cout_seg, cin_seg)
         ctx.has_skip = skip is not None
         return out
 
     @staticmethod
     def backward(ctx, g):
         x, y, out, mean, scale, pwd = ctx.saved_tensors
+        cout, cin, cout_seg, cin_seg = ctx.dims
+        cout_p = padded_dim(cout, cout_seg)
         sd = x.dtype
         g = as_grad(g, sd)
-        cout = ctx.cout
-        u = out[:, :cout] if ctx.has_skip else out
-        gu = g[:, :cout] if ctx.has_skip else g
-        gskip = g[:, cout:] if ctx.has_skip else None
+        u = out[:, :cout_p] if ctx.has_skip else out
+        gu = g[:, :cout_p] if ctx.has_skip else g
+        gskip = g[:, cout_p:] if ctx.has_skip else None
         dy, _ = in_lrelu_bwd(gu, u, y, mean, scale, zero_far=True)
         with _OnSide(x.device):
-            gw = convt_wgrad(x, dy)
-            gb = channel_sum(dy)
+            # the ConvTranspose3d weight is [Cin][Cout][27]: its outer dimension is the module's in_channels
+            gw = unpad_wgrad(convt_wgrad(x, dy), cin, cout, cin_seg, cout_seg)
+            gb = channel_sum(dy)[:cout]
         gx = None
         if ctx.needs_input_grad[0]:
             gx = convt_dgrad(dy, pwd, tuple(x.shape))
         _join(x.device, gw, gb)
-        return gx, gw, gb, gskip
+        return gx, gw, gb, gskip, None

@@ -82,6 +82,10 @@ extern "C" int ru3d_pack_weight(const float* src, void* dst, int cout, int cin, 
     return pack_generic_launch(src, dst, kin, kout, taps, s_o, s_i, 0, dtype, as_stream(stream));
 }
 
+static int pad32(int c) { return (c + 31) / 32 * 32; }
+// packed extent of a module dimension of `real` channels made of segments of `seg` (0: no padding)
+static int padded_dim(int real, int seg) { return seg > 0 ? (real / seg) * pad32(seg) : real; }
+
 extern "C" int ru3d_pack_weights(const ru3d_pack_item* items, int count, int dtype, void* stream) {
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(items && count > 0 && count <= RU3D_PACK_MAX, "pack_weights: count must be 1..%d", RU3D_PACK_MAX);
@@ -91,21 +95,50 @@ extern "C" int ru3d_pack_weights(const ru3d_pack_item* items, int count, int dty
     for (int i = 0; i < count; i++) {
         const ru3d_pack_item& it = items[i];
         RU3D_REQUIRE(it.src && it.dst && it.cout > 0 && it.cin > 0 && (it.k == 1 || it.k == 3) &&
-                         (it.stride == 1 || it.stride == 2) && it.role >= 0 && it.role <= 3,
+                         (it.stride == 1 || it.stride == 2) && it.role >= 0 && it.role <= RU3D_ROLE_BIAS,
                      "pack_weights: bad item %d", i);
-        const int taps = it.k * it.k * it.k;
-        int kin, kout;
-        int64_t s_o, s_i;
-        role_channels(it.cout, it.cin, it.role, &kin, &kout, &s_o, &s_i, taps);
+        RU3D_REQUIRE(it.cout_seg >= 0 && it.cin_seg >= 0 && (it.cout_seg == 0 || it.cout % it.cout_seg == 0) &&
+                         (it.cin_seg == 0 || it.cin % it.cin_seg == 0),
+                     "pack_weights: item %d: segments (%d, %d) do not divide (%d, %d)", i, it.cout_seg, it.cin_seg,
+                     it.cout, it.cin);
         PackOne& p = b.item[i];
         p.src = it.src;
         p.dst = it.dst;
-        p.cin = kin; p.cout = kout; p.taps = taps; p.s_o = s_o; p.s_i = s_i;
-        p.mfma = role_uses_mfma(kin, kout, it.k, it.stride, it.role, dtype) ? 1 : 0;
-        p.cout_pad = generic_cout_pad(kout);
-        p.total = p.mfma ? (int64_t)taps * kin * kout : (int64_t)taps * kin * p.cout_pad;
+        if (it.role == RU3D_ROLE_BIAS) {
+            p.mfma = 2;
+            p.cout = padded_dim(it.cout, it.cout_seg);
+            p.cin = 1; p.taps = 1; p.cout_pad = p.cout; p.s_o = 1; p.s_i = 1;
+            p.co_real = it.cout_seg; p.co_pad = it.cout_seg ? pad32(it.cout_seg) : 0;
+            p.ci_real = 0; p.ci_pad = 0;
+            p.total = p.cout;
+            continue;
+        }
+        const int taps = it.k * it.k * it.k;
+        int kin, kout;
+        int64_t s_o, s_i;
+        role_channels(it.cout, it.cin, it.role, &kin, &kout, &s_o, &s_i, taps);   // strides: of the REAL source
+        // which module dimension is the kernel's input / output channel dimension
+        const bool in_is_cin = (it.role == RU3D_ROLE_CONV_FWD || it.role == RU3D_ROLE_CONVT_FWD);
+        const int kin_seg = in_is_cin ? it.cin_seg : it.cout_seg, kout_seg = in_is_cin ? it.cout_seg : it.cin_seg;
+        const int kin_p = padded_dim(kin, kin_seg), kout_p = padded_dim(kout, kout_seg);
+        p.cin = kin_p; p.cout = kout_p; p.taps = taps; p.s_o = s_o; p.s_i = s_i;
+        p.ci_real = kin_seg; p.ci_pad = kin_seg ? pad32(kin_seg) : 0;
+        p.co_real = kout_seg; p.co_pad = kout_seg ? pad32(kout_seg) : 0;
+        p.mfma = role_uses_mfma(kin_p, kout_p, it.k, it.stride, it.role, dtype) ? 1 : 0;
+        p.cout_pad = generic_cout_pad(kout_p);
+        p.total = p.mfma ? (int64_t)taps * kin_p * kout_p : (int64_t)taps * kin_p * p.cout_pad;
     }
     return pack_batch_launch(b, dtype, as_stream(stream));
+}
+
+extern "C" int ru3d_unpad_weight_grad(const float* src, float* dst, int cout, int cin, int taps, int cout_seg,
+                                      int cin_seg, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(src && dst && cout > 0 && cin > 0 && taps > 0, "unpad_weight_grad: bad argument");
+    RU3D_REQUIRE(cout_seg >= 0 && cin_seg >= 0 && (cout_seg == 0 || cout % cout_seg == 0) &&
+                     (cin_seg == 0 || cin % cin_seg == 0), "unpad_weight_grad: bad segments");
+    return unpad_weight_launch(src, dst, cout, cin, taps, cout_seg, cout_seg ? pad32(cout_seg) : 0, cin_seg,
+                               cin_seg ? pad32(cin_seg) : 0, padded_dim(cin, cin_seg), as_stream(stream));
 }
 
 static int run_conv(const ru3d_tensor* x, const void* w, const float* bias, const ru3d_tensor* res,

@@ -27,7 +27,8 @@ struct WgradGeom {
 struct PackOne {
     const float* src;
     void* dst;
-    int cin, cout, taps, mfma, cout_pad;
+    int cin, cout, taps, mfma, cout_pad;   // cin / cout: PACKED (kernel-side) channel counts; mfma: 0 generic, 1 MFMA, 2 bias
+    int co_real, co_pad, ci_real, ci_pad;  // channel padding per segment (pad == 0: none), see pack_src_index
     int64_t s_o, s_i, total;
 };
 struct PackBatch {
@@ -35,6 +36,8 @@ struct PackBatch {
     PackOne item[RU3D_PACK_MAX];
 };
 int pack_batch_launch(const PackBatch& b, int dtype, hipStream_t st);
+int unpad_weight_launch(const float* src, float* dst, int cout, int cin, int taps, int co_real, int co_pad, int ci_real,
+                        int ci_pad, int cin_p, hipStream_t st);
 
 // conv_generic.hip
 int generic_cot(int cout);

@@ -180,24 +180,49 @@ int pack_generic_launch(const float* src, void* dst, int cin, int cout, int taps
 // (16*taps or 32*taps floats) and writes one 1-KiB fragment per tap.  The element-wise gather it replaces touched a
 // different 64-byte line with every 4-byte read.
 #define PACK_TILE_FLOATS (32 * (16 * 27 + 1))   // >= 16 * (32 * 27 + 1)
+// Channel padding (PackOne::*_seg): a channel dimension of the packed weight may be made of segments of `real`
+// source channels each padded with zeros to `pad` packed channels (F = 30 widths on the MFMA kernels: 30 -> 32,
+// and the decoder's concat input 30 | 30 -> 32 | 32).  pad == 0: the dimension is packed as it is.
+__device__ __forceinline__ int pack_src_index(int p, int real, int pad) {
+    if (pad == 0) return p;
+    const int seg = p / pad, off = p - seg * pad;
+    return off < real ? seg * real + off : -1;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_batch_kernel(PackBatch b) {
     __shared__ float tile[PACK_TILE_FLOATS];   // 32 rows of 16*taps(+1) floats, or 16 rows of 32*taps(+1)
     const PackOne& p = b.item[blockIdx.y];
     T* dst = (T*)p.dst;
     const int taps = p.taps;
+    if (p.mfma == 2) {   // bias vector: fp32, zero-padded per segment
+        float* out = (float*)p.dst;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < p.cout; i += gridDim.x * 256) {
+            const int sc = pack_src_index(i, p.co_real, p.co_pad);
+            out[i] = sc >= 0 ? p.src[sc] : 0.f;
+        }
+        return;
+    }
     const bool rows_co = (p.s_i == taps), rows_ci = (p.s_o == taps);
     if (p.mfma && sizeof(T) == 2 && taps <= 27 && (rows_co || rows_ci)) {
         const int KS = p.cin / 16, NTT = p.cout / 32;
         const int nrows = rows_co ? 32 : 16, rowlen = (rows_co ? 16 : 32) * taps, pitch = rowlen + 1;
         for (int unit = blockIdx.x; unit < KS * NTT; unit += gridDim.x) {
             const int ks = unit / NTT, nt = unit % NTT;
-            const float* base = p.src + (int64_t)(nt * 32) * p.s_o + (int64_t)(ks * 16) * p.s_i;
+            // a 32-channel (16-channel) block never straddles a padded segment (segments are multiples of 32):
+            // first source channel of the block and the number of real channels in it, per dimension
+            const int co_s = pack_src_index(nt * 32, p.co_real, p.co_pad);
+            const int ci_s = pack_src_index(ks * 16, p.ci_real, p.ci_pad);
+            int co_n = 32, ci_n = 16;
+            if (p.co_pad) co_n = co_s < 0 ? 0 : min(32, p.co_real - (nt * 32) % p.co_pad);
+            if (p.ci_pad) ci_n = ci_s < 0 ? 0 : min(16, p.ci_real - (ks * 16) % p.ci_pad);
+            const float* base = p.src + (int64_t)(co_s < 0 ? 0 : co_s) * p.s_o + (int64_t)(ci_s < 0 ? 0 : ci_s) * p.s_i;
             const int64_t row_stride = rows_co ? p.s_o : p.s_i;
+            const int row_n = rows_co ? co_n : ci_n, col_n = (rows_co ? ci_n : co_n) * taps;
             __syncthreads();
             for (int e = threadIdx.x; e < nrows * rowlen; e += 256) {
                 const int r = e / rowlen, j = e - r * rowlen;
-                tile[r * pitch + j] = base[(int64_t)r * row_stride + j];
+                tile[r * pitch + j] = (r < row_n && j < col_n) ? base[(int64_t)r * row_stride + j] : 0.f;
             }
             __syncthreads();
             for (int e = threadIdx.x; e < taps * 64; e += 256) {
@@ -226,18 +251,44 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(PackBatch b) {
             t /= NTT;
             const int ks = (int)(t % KS);
             const int tap = (int)(t / KS);
-            const int co = nt * 32 + (lane & 31);
-            const int ci = ks * 16 + 8 * (lane >> 5) + j;
-            v = p.src[co * p.s_o + ci * p.s_i + tap];
+            const int co = pack_src_index(nt * 32 + (lane & 31), p.co_real, p.co_pad);
+            const int ci = pack_src_index(ks * 16 + 8 * (lane >> 5) + j, p.ci_real, p.ci_pad);
+            if (co >= 0 && ci >= 0) v = p.src[co * p.s_o + ci * p.s_i + tap];
         } else {
             const int co = (int)(i % p.cout_pad);
             const int64_t t = i / p.cout_pad;
-            const int ci = (int)(t % p.cin);
+            const int ci = pack_src_index((int)(t % p.cin), p.ci_real, p.ci_pad);
             const int tap = (int)(t / p.cin);
-            if (co < p.cout) v = p.src[co * p.s_o + ci * p.s_i + tap];
+            const int cs = co < p.cout ? pack_src_index(co, p.co_real, p.co_pad) : -1;
+            if (cs >= 0 && ci >= 0) v = p.src[cs * p.s_o + ci * p.s_i + tap];
         }
         dst[i] = from_f32<T>(v);
     }
+}
+
+// dst[co][ci][tap] = src[co_p][ci_p][tap]: drops the zero rows / columns of a weight gradient computed on padded channels
+__global__ __launch_bounds__(256) void unpad_weight_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                           int cout, int cin, int taps, int co_real, int co_pad,
+                                                           int ci_real, int ci_pad, int cin_p) {
+    const int64_t total = (int64_t)cout * cin * taps;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int tap = (int)(i % taps);
+        const int64_t t = i / taps;
+        const int ci = (int)(t % cin), co = (int)(t / cin);
+        const int cop = co_pad ? (co / co_real) * co_pad + co % co_real : co;
+        const int cip = ci_pad ? (ci / ci_real) * ci_pad + ci % ci_real : ci;
+        dst[i] = src[((int64_t)cop * cin_p + cip) * taps + tap];
+    }
+}
+
+int unpad_weight_launch(const float* src, float* dst, int cout, int cin, int taps, int co_real, int co_pad, int ci_real,
+                        int ci_pad, int cin_p, hipStream_t st) {
+    const int64_t total = (int64_t)cout * cin * taps;
+    int64_t blocks = (total + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(unpad_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, cout, cin, taps, co_real,
+                       co_pad, ci_real, ci_pad, cin_p);
+    return ru3d_check_launch("unpad_weight_grad");
 }
 
 int pack_batch_launch(const PackBatch& b, int dtype, hipStream_t st) {

@@ -166,8 +166,26 @@ __device__ __forceinline__ void finalize_sums(const double* __restrict__ part, i
     const int cx = threadIdx.x % FIN_CX, ky = threadIdx.x / FIN_CX;
     double a1 = 0.0, a2 = 0.0;
     if (ok) {
-        for (int r = ky; r < rows; r += FIN_KY) {
-            const double* pp = part + (int64_t)r * row_stride + (int64_t)c * 2;
+        // eight independent partial rows in flight per lane (a serial chain of dependent loads cost ~10 us on the
+        // 512-chunk tensors); the order of the additions is fixed, so the result is still deterministic
+        const double* base = part + (int64_t)c * 2;
+        int r = ky;
+        for (; r + 7 * FIN_KY < rows; r += 8 * FIN_KY) {
+            double u1[8], u2[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const double* pp = base + (int64_t)(r + j * FIN_KY) * row_stride;
+                u1[j] = pp[0];
+                u2[j] = pp[1];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                a1 += u1[j];
+                a2 += u2[j];
+            }
+        }
+        for (; r < rows; r += FIN_KY) {
+            const double* pp = base + (int64_t)r * row_stride;
             a1 += pp[0];
             a2 += pp[1];
         }

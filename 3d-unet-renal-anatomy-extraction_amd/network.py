@@ -30,13 +30,27 @@ _DEFAULT_DTYPE = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch
                   "bfloat16": torch.bfloat16}[os.environ.get("RU3D_DTYPE", "fp32").lower()]
 
 
+_STORAGE_DTYPES = (torch.float32, torch.bfloat16)
+
+
 def set_compute_dtype(model, dtype):
     """Select the activation/weight storage dtype of every native U-Net inside `model`."""
-    if dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError("compute dtype must be torch.float32 or torch.bfloat16")
+    if dtype not in _STORAGE_DTYPES:
+        raise ValueError("compute dtype must be one of %s" % (_STORAGE_DTYPES,))
     for m in model.modules():
         if isinstance(m, Unet):
             m.compute_dtype = dtype
+            m._configure_native()
+    return model
+
+
+def set_checkpointing(model, enabled=True):
+    """Activation checkpointing of the native ResBlocks (BASELINE config 5): keep only each block's input, output
+    and InstanceNorm statistics for backward and recompute its three interior tensors there.  Gradients are
+    bit-identical to the un-checkpointed run; saved activations drop to roughly two fifths."""
+    for m in model.modules():
+        if isinstance(m, ResBlock):
+            m._checkpoint = bool(enabled)
     return model
 
 
@@ -209,11 +223,12 @@ class ConvTrans3D(nn.Module):
             norm_op(out_channels, **norm_kwargs),
             nonlin_op(**nonlin_kwargs))
         self._native = _is_plain_in(self.up[2]) and _is_plain_lrelu(self.up[3])
+        self._pad = False          # set by Unet: activations carry channels zero-padded to multiples of 32
 
     def forward(self, x, skip=None):
         """`skip` is an extension used by UpConcat: returns cat((up(x), skip), dim=1) written in place."""
         if self._native and x.is_cuda:
-            return ops.UpFn.apply(x, self.up[0].weight, self.up[0].bias, skip)
+            return ops.UpFn.apply(x, self.up[0].weight, self.up[0].bias, skip, self._pad)
         if self._native:
             N.require_device(x, "ConvTrans3D input")
         y = self.up(x)
@@ -267,6 +282,9 @@ class ResBlock(nn.Module):
                         and _is_plain_lrelu(self.nonlin)
                         and (self.dropout is None or type(self.dropout) is nn.Dropout3d))
         self._forced_keep = None   # tests: inject a recorded [N, C] keep mask instead of drawing one
+        self._pad = False          # set by Unet: activations carry channels zero-padded to multiples of 32
+        self._in_segs = 1          # set by Unet: 2 when the input is the padded concat [up | skip]
+        self._checkpoint = False   # set_checkpointing(): recompute the block's interior in backward
 
     @property
     def uses_skip_conv(self):
@@ -277,19 +295,24 @@ class ResBlock(nn.Module):
             return None
         p = float(self.dropout.p)
         n = x.shape[0]
+        c = ops.cpad(self.out_channels) if self._pad else self.out_channels
         if self._forced_keep is not None:
-            keep = self._forced_keep.to(device=x.device, dtype=torch.float32).reshape(-1)
-            return (keep / (1.0 - p)).contiguous()
+            keep = self._forced_keep.to(device=x.device, dtype=torch.float32).reshape(n, -1)
+            if keep.shape[1] != c:      # pad lanes hold exact zeros whatever their factor is
+                keep = torch.nn.functional.pad(keep, (0, c - keep.shape[1]), value=1.0)
+            return (keep.reshape(-1) / (1.0 - p)).contiguous()
         if p == 0.0:
             return None
-        return ops.dropout_scale(n, self.out_channels, p, x.device)
+        return ops.dropout_scale(n, c, p, x.device)
 
     def forward(self, x):
         if self._native and x.is_cuda:
             skip_w = self.skip_conv.weight if self.uses_skip_conv else None
             skip_b = self.skip_conv.bias if self.uses_skip_conv else None
             return ops.ResBlockFn.apply(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
-                                        skip_w, skip_b, self.stride, self._drop_scale(x))
+                                        skip_w, skip_b, self.stride, self._drop_scale(x),
+                                        self._in_segs if self._pad else 0,
+                                        self._checkpoint and torch.is_grad_enabled())
         if self._native:
             N.require_device(x, "ResBlock input")
         skip = self.skip_conv(x) if self.uses_skip_conv else x
@@ -358,17 +381,59 @@ class Unet(nn.Module):
         self.fc = conv_op(pf[num_pairs - 1][1], out_channels, kernel_size=1)
         self.compute_dtype = _DEFAULT_DTYPE
         self._native_io = _is_plain_conv3(self.conv) and _is_plain_conv1(self.fc)
+        self._pad = False
+        self._configure_native()
+
+    def _native_chain(self):
+        """The native blocks between stem and head, or None when any block on the path is a torch module."""
+        blocks = []
+        for blk in list(self.pool_blocks) + list(self.encode_blocks) + list(self.decode_blocks):
+            if isinstance(blk, ResBlockStack):
+                blocks += list(blk.res_blocks)
+            else:
+                blocks.append(blk)
+        for blk in blocks:
+            if not (isinstance(blk, ResBlock) and blk._native):
+                return None
+        for up in self.up_blocks:
+            if not (isinstance(up, UpConcat) and not up.attention and isinstance(up.conv_trans, ConvTrans3D)
+                    and up.conv_trans._native):
+                return None
+            blocks.append(up.conv_trans)
+        return blocks if self._native_io else None
+
+    def _configure_native(self):
+        """Channel padding: with a 16-bit storage dtype, widths that are not multiples of 32 (the reference's default
+        num_features = 30 gives 30/60/120/240/480, network.py:107) run on the MFMA kernels with every activation
+        between stem and head zero-padded to the next multiple of 32 (the pad lanes stay exact zeros through conv,
+        InstanceNorm, LeakyReLU and their gradients; weights are packed with zero rows/columns and weight gradients
+        are cut back to the parameters' shapes).  Forward hooks on inner blocks see the padded channel counts."""
+        chain = self._native_chain()
+        widths = []
+        if chain is not None:
+            for blk in chain:
+                widths += [blk.in_channels, blk.out_channels]
+        pad = (chain is not None and self.compute_dtype != torch.float32 and any(c % 32 for c in widths)
+               and os.environ.get("RU3D_PAD_CHANNELS", "1") != "0")
+        self._pad = pad
+        for blk in (chain or []):
+            blk._pad = pad
+        for blk in self.decode_blocks:      # their input is cat((up, skip)): two padded segments
+            first = blk.res_blocks[0] if isinstance(blk, ResBlockStack) else blk
+            if isinstance(first, ResBlock):
+                first._in_segs = 2
 
     def _stem(self, x):
         if self._native_io and x.is_cuda:
-            return ops.ConvFn.apply(x, self.conv.weight, self.conv.bias, 1, self.compute_dtype, self.compute_dtype)
+            return ops.ConvFn.apply(x, self.conv.weight, self.conv.bias, 1, self.compute_dtype, self.compute_dtype,
+                                    False, self._pad)
         if self._native_io:
             N.require_device(x, "Unet input")
         return self.conv(x)
 
     def _head(self, x):
         if self._native_io and x.is_cuda:
-            return ops.ConvFn.apply(x, self.fc.weight, self.fc.bias, 1, x.dtype, torch.float32)
+            return ops.ConvFn.apply(x, self.fc.weight, self.fc.bias, 1, x.dtype, torch.float32, self._pad, False)
         return self.fc(x)
 
     def forward(self, x):

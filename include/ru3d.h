@@ -44,7 +44,8 @@ enum {
     RU3D_ROLE_CONV_FWD = 0,    /* nn.Conv3d weight [Cout][Cin][k^3]          -> forward          */
     RU3D_ROLE_CONV_DGRAD = 1,  /* nn.Conv3d weight                            -> input gradient   */
     RU3D_ROLE_CONVT_FWD = 2,   /* nn.ConvTranspose3d weight [Cin][Cout][k^3]  -> forward          */
-    RU3D_ROLE_CONVT_DGRAD = 3  /* nn.ConvTranspose3d weight                   -> input gradient   */
+    RU3D_ROLE_CONVT_DGRAD = 3, /* nn.ConvTranspose3d weight                   -> input gradient   */
+    RU3D_ROLE_BIAS = 4         /* bias vector [Cout] -> fp32 [Cout padded] (ru3d_pack_weights only)  */
 };
 
 /* loss kinds: which reference module the finalize step reproduces */
@@ -74,14 +75,27 @@ size_t ru3d_packed_weight_bytes(int cout, int cin, int k, int stride, int role, 
 int ru3d_pack_weight(const float* src, void* dst, int cout, int cin, int k, int stride, int role, int dtype,
                      void* stream);
 
-/* Same, for up to RU3D_PACK_MAX weights in ONE launch (a ResBlock's three convs x {forward, dgrad}). */
-#define RU3D_PACK_MAX 8
+/* Same, for up to RU3D_PACK_MAX weights in ONE launch (a ResBlock's three convs x {forward, dgrad} + biases).
+ * Channel padding: widths that are not multiples of 32 (the reference's default num_features = 30,
+ * network.py:107, gives 30/60/120/240/480) run on the MFMA kernels with activations padded to the next multiple
+ * of 32 and exact zeros in the pad lanes.  cout_seg / cin_seg != 0 ask for the packed weight of such a layer:
+ * that dimension of the module's weight consists of (dim / seg) segments of `seg` real channels, each padded with
+ * zero rows / columns to the next multiple of 32 (cin_seg = 30 for cin = 60 is the decoder's concat input
+ * 30 | 30 -> 32 | 32, network.py:350).  dst is then ru3d_packed_weight_bytes(padded cout, padded cin, ...) long.
+ * Role RU3D_ROLE_BIAS pads a bias vector the same way (src fp32 [cout], dst fp32 [padded cout]; k = 1). */
+#define RU3D_PACK_MAX 12
 typedef struct ru3d_pack_item {
     const float* src; /* fp32 weight, reference layout                  */
     void* dst;        /* packed output, ru3d_packed_weight_bytes() long  */
     int32_t cout, cin, k, stride, role;
+    int32_t cout_seg, cin_seg; /* 0 = no padding of that dimension       */
 } ru3d_pack_item;
 int ru3d_pack_weights(const ru3d_pack_item* items, int count, int dtype, void* stream);
+
+/* Inverse of the channel padding for a weight gradient: src = fp32 [cout_p][cin_p][taps] as the wgrad entry points
+ * write it for padded activations, dst = fp32 [cout][cin][taps] (the parameter's shape), segments as above. */
+int ru3d_unpad_weight_grad(const float* src, float* dst, int cout, int cin, int taps, int cout_seg, int cin_seg,
+                           void* stream);
 
 /* ------------------------------------------------------------------ convolutions ------------ */
 /* nn.Conv3d(k in {1,3}, stride in {1,2}, padding=k/2) forward (network.py:394-395,403,541-547).
