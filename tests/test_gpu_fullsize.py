@@ -147,3 +147,78 @@ def test_config2_forward_fp32_vs_cpu_oracle_full_patch():
         a, b = (got.argmax(1) == c).float(), (ref.argmax(1) == c).long()
         if b.sum() > 0:
             assert O.tversky(a, b).item() > 0.999
+
+
+# --------------------------------------------------------------------------- BASELINE config 5 (F = 64, P = 5, 192^3)
+S5 = 192
+
+
+def test_config5_tap_count_identities_192_cubed_64_channels():
+    """64 -> 64 channels on the 1 x 192^3 grid (453 M elements per tensor: every index product of the kernels is
+    exercised close to 2^31), and the 2048-channel bottleneck on its 6^3 grid."""
+    n, c = 1, 64
+    x = N.new_act(n, c, S5, S5, S5, torch.bfloat16, DEV)
+    x.fill_(1.0)
+    w = torch.full((c, c, 3, 3, 3), 1.0 / c, device=DEV)
+    pw = ops.pack_weight(w, N.ROLE_CONV_FWD, torch.bfloat16, 1)
+    y = ops.conv_fwd(x, pw, None, c, 3, 1)
+    counts = _valid_counts(S5, S5, S5).to(DEV)
+    assert torch.equal(y.float(), counts[None, None].expand(n, c, S5, S5, S5))
+    del y
+    gw = ops.conv_wgrad(x, x, 3, 1)
+    ax = torch.tensor([S5 - 1.0, S5, S5 - 1.0])
+    expect = n * ax[:, None, None] * ax[None, :, None] * ax[None, None, :]
+    assert torch.equal(gw.cpu(), expect[None, None].expand(c, c, 3, 3, 3))
+    del x, gw
+    # bottleneck: 2048 -> 2048 on 6^3 (sums of 2048 * 27 terms of 2^-11 are exact in fp32)
+    cb, sb = 2048, 6
+    xb = N.new_act(1, cb, sb, sb, sb, torch.bfloat16, DEV)
+    xb.fill_(1.0)
+    wb = torch.full((cb, cb, 3, 3, 3), 1.0 / cb, device=DEV)
+    pwb = ops.pack_weight(wb, N.ROLE_CONV_FWD, torch.bfloat16, 1)
+    yb = ops.conv_fwd(xb, pwb, None, cb, 3, 1)
+    cnt = _valid_counts(sb, sb, sb).to(DEV)
+    assert torch.equal(yb.float(), cnt[None, None].expand(1, cb, sb, sb, sb))
+    gwb = ops.conv_wgrad(xb, xb, 3, 1)
+    axb = torch.tensor([sb - 1.0, sb, sb - 1.0])
+    eb = axb[:, None, None] * axb[None, :, None] * axb[None, None, :]
+    assert torch.equal(gwb[:64, :64].cpu(), eb[None, None].expand(64, 64, 3, 3, 3))
+    assert torch.equal(gwb[-1, -1].cpu(), eb)
+
+
+def test_config5_training_step_deterministic_and_checkpoint_bit_equal():
+    """ResUnet3D(5, 64, 1, 3) on 1 x 192^3 in bf16 (1.86 G parameters): two runs give the same bits, and the
+    checkpointed run (ResBlock interiors recomputed in backward) gives the same bits again with less memory held."""
+    torch.manual_seed(0)
+    model = network.ResUnet3D(5, 64, 1, 3).to(DEV).eval()
+    network.set_compute_dtype(model, torch.bfloat16)
+    x = O.synth_image((1, 1, S5, S5, S5), 99).to(DEV)
+    y = torch.randint(0, 3, (1, S5, S5, S5), generator=torch.Generator().manual_seed(2)).to(DEV)
+    crit = L.HybirdLoss(weight_v=[1, 10, 20])
+    keys = ["net.conv.weight", "net.encode_blocks.0.res_blocks.0.conv1.weight", "net.pool_blocks.2.conv1.weight",
+            "net.encode_blocks.5.res_blocks.4.conv2.weight", "net.up_blocks.0.conv_trans.up.0.weight",
+            "net.decode_blocks.0.conv1.weight", "net.fc.weight"]
+    params = dict(model.named_parameters())
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        logits = model(x)
+        loss = crit(logits, y)
+        held = torch.cuda.memory_allocated() - base
+        loss.backward()
+        torch.cuda.synchronize()
+        out = (logits.detach().clone(), float(loss.detach()), {k: params[k].grad.clone() for k in keys}, held)
+        assert all(torch.isfinite(g).all() for g in out[2].values())
+        return out
+
+    a = run()
+    b = run()
+    network.set_checkpointing(model, True)
+    c = run()
+    for other in (b, c):
+        assert torch.equal(a[0], other[0]) and a[1] == other[1]
+        for k in keys:
+            assert torch.equal(a[2][k], other[2][k]), k
+    assert c[3] < 0.62 * a[3], (a[3], c[3])
