@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RU3D_LIB", os.path.join(_HERE, "libru3d.so"))
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 LABEL_I64, LABEL_U8 = 0, 1
 ROLE_CONV_FWD, ROLE_CONV_DGRAD, ROLE_CONVT_FWD, ROLE_CONVT_DGRAD, ROLE_BIAS = 0, 1, 2, 3, 4
 LOSS_HYBIRD, LOSS_DICELOSS, LOSS_FOCAL, LOSS_DICE = 0, 1, 2, 3
@@ -78,6 +78,7 @@ SIGNATURES = {
     "ru3d_predict_merge": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ru3d_adam_multi": (_i, [_vp, _vp, _i, _i, _f, _f, _f, _f, _f, _f, _f, _vp]),
     "ru3d_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp]),
+    "ru3d_grad_scale_check": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp]),
     "ru3d_comm_unique_id": (_i, [_vp]),
     "ru3d_comm_init": (_i, [ctypes.POINTER(_vp), _vp, _i, _i, _i]),
     "ru3d_comm_allreduce": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
@@ -134,7 +135,9 @@ def dtype_code(dt):
         return F32
     if dt == torch.bfloat16:
         return BF16
-    raise Ru3dError("ru3d: unsupported storage dtype %s (float32 or bfloat16)" % dt)
+    if dt == torch.float16:
+        return F16
+    raise Ru3dError("ru3d: unsupported storage dtype %s (float32, bfloat16 or float16)" % dt)
 
 
 def require_device(t, what="tensor"):

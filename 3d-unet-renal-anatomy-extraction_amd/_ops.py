@@ -192,7 +192,7 @@ def set_probe(p):
 
 def _conv_ws(dsrc, ddst, k, stride, dtype, device):
     """(pointer, bytes) of the optional conv scratch (split-K partials on the deepest level), caller-owned."""
-    if k != 3 or stride != 1 or dtype != torch.bfloat16:
+    if k != 3 or stride != 1 or dtype == torch.float32:
         return None, 0
     need = N.lib.ru3d_conv3d_workspace_bytes(ref(dsrc), ref(ddst), k, stride, N.dtype_code(dtype))
     if need == 0:

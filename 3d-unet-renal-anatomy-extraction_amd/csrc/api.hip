@@ -6,6 +6,8 @@
 #include "conv.h"
 #include <string>
 
+#ifndef RU3D_STORAGE_F16   // error plumbing and version: defined once, by the bf16 build
+
 static thread_local std::string g_last_error;
 
 int ru3d_fail(int code, const char* fmt, ...) {
@@ -29,8 +31,11 @@ int ru3d_check_launch(const char* what) {
 
 extern "C" int ru3d_version(void) { return RU3D_VERSION; }
 extern "C" const char* ru3d_last_error(void) { return g_last_error.c_str(); }
+#endif
 
-static bool dtype_ok(int d) { return d == RU3D_F32 || d == RU3D_BF16; }
+namespace RU3D_NS {
+
+static bool dtype_ok(int d) { return d == RU3D_F32 || d == RU3D_BF16; }   // fp32 or this build's 16-bit type
 static int conv_out(int in, int k, int s) { return (in + 2 * (k / 2) - k) / s + 1; }
 
 // channels (in', out') of the data-movement kernel that consumes a packed weight
@@ -55,6 +60,7 @@ static bool role_uses_mfma(int kin, int kout, int k, int stride, int role, int d
 }
 
 extern "C" size_t ru3d_packed_weight_bytes(int cout, int cin, int k, int stride, int role, int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_packed_weight_bytes_f16(cout, cin, k, stride, role, dtype));
     if (cout <= 0 || cin <= 0 || (k != 1 && k != 3) || (stride != 1 && stride != 2) || role < 0 || role > 3 ||
         !dtype_ok(dtype))
         return 0;
@@ -68,6 +74,7 @@ extern "C" size_t ru3d_packed_weight_bytes(int cout, int cin, int k, int stride,
 
 extern "C" int ru3d_pack_weight(const float* src, void* dst, int cout, int cin, int k, int stride, int role, int dtype,
                                 void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_pack_weight_f16(src, dst, cout, cin, k, stride, role, dtype, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(src && dst, "pack_weight: null pointer");
     RU3D_REQUIRE(cout > 0 && cin > 0 && (k == 1 || k == 3) && (stride == 1 || stride == 2),
@@ -87,6 +94,7 @@ static int pad32(int c) { return (c + 31) / 32 * 32; }
 static int padded_dim(int real, int seg) { return seg > 0 ? (real / seg) * pad32(seg) : real; }
 
 extern "C" int ru3d_pack_weights(const ru3d_pack_item* items, int count, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_pack_weights_f16(items, count, dtype, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(items && count > 0 && count <= RU3D_PACK_MAX, "pack_weights: count must be 1..%d", RU3D_PACK_MAX);
     RU3D_REQUIRE(dtype_ok(dtype), "pack_weights: bad dtype");
@@ -131,6 +139,7 @@ extern "C" int ru3d_pack_weights(const ru3d_pack_item* items, int count, int dty
     return pack_batch_launch(b, dtype, as_stream(stream));
 }
 
+#ifndef RU3D_STORAGE_F16
 extern "C" int ru3d_unpad_weight_grad(const float* src, float* dst, int cout, int cin, int taps, int cout_seg,
                                       int cin_seg, void* stream) {
     Ru3dDeviceGuard dev_guard(stream);
@@ -140,6 +149,7 @@ extern "C" int ru3d_unpad_weight_grad(const float* src, float* dst, int cout, in
     return unpad_weight_launch(src, dst, cout, cin, taps, cout_seg, cout_seg ? pad32(cout_seg) : 0, cin_seg,
                                cin_seg ? pad32(cin_seg) : 0, padded_dim(cin, cin_seg), as_stream(stream));
 }
+#endif
 
 static int run_conv(const ru3d_tensor* x, const void* w, const float* bias, const ru3d_tensor* res,
                     const ru3d_tensor* y, int k, int stride, int transposed, int flip, int zero_far, int dtype,
@@ -168,6 +178,7 @@ static bool res_ok(const ru3d_tensor* res, const ru3d_tensor* y) {
 // Optional scratch of a conv launch (split-K partials of the deepest level); 0 for most shapes.  The same figure serves
 // the input gradient of a stride-1 conv (call it with (dy, dx)).
 extern "C" size_t ru3d_conv3d_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* y, int k, int stride, int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_workspace_bytes_f16(x, y, k, stride, dtype));
     if (!tensor_ok(x) || !tensor_ok(y) || dtype != RU3D_BF16 || k != 3 || stride != 1) return 0;
     if (!mfma_conv_eligible(x->c, y->c, k, dtype, dtype)) return 0;
     ConvGeom g;
@@ -184,6 +195,7 @@ extern "C" size_t ru3d_conv3d_workspace_bytes(const ru3d_tensor* x, const ru3d_t
 extern "C" int ru3d_conv3d_fwd(const ru3d_tensor* x, const void* w_packed, const float* bias, const ru3d_tensor* res,
                                const ru3d_tensor* y, int k, int stride, int dtype, int y_dtype, void* ws,
                                size_t ws_bytes, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_fwd_f16(x, w_packed, bias, res, y, k, stride, dtype, y_dtype, ws, ws_bytes, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(x) && tensor_ok(y) && w_packed, "conv3d_fwd: bad tensor/weight");
     RU3D_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "conv3d_fwd: k=%d stride=%d unsupported", k, stride);
@@ -216,6 +228,7 @@ static bool fwd_in_fused(const ru3d_tensor* x, const ru3d_tensor* y, int k, int 
 
 extern "C" size_t ru3d_conv3d_fwd_in_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* y, int k, int stride,
                                                      int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_fwd_in_workspace_bytes_f16(x, y, k, stride, dtype));
     if (!tensor_ok(x) || !tensor_ok(y)) return 0;
     size_t need = ru3d_reduce_workspace_bytes(y);
     if (fwd_in_fused(x, y, k, stride, dtype)) {
@@ -230,6 +243,7 @@ extern "C" size_t ru3d_conv3d_fwd_in_workspace_bytes(const ru3d_tensor* x, const
 extern "C" int ru3d_conv3d_fwd_in(const ru3d_tensor* x, const void* w_packed, const float* bias, const ru3d_tensor* y,
                                   int k, int stride, int dtype, const float* drop_scale, float* mean, float* scale,
                                   void* ws, size_t ws_bytes, float eps, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_fwd_in_f16(x, w_packed, bias, y, k, stride, dtype, drop_scale, mean, scale, ws, ws_bytes, eps, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(x) && tensor_ok(y) && w_packed && mean && scale && ws, "conv3d_fwd_in: bad argument");
     RU3D_REQUIRE(ws_bytes >= ru3d_conv3d_fwd_in_workspace_bytes(x, y, k, stride, dtype), "conv3d_fwd_in: workspace too small");
@@ -252,6 +266,7 @@ extern "C" int ru3d_conv3d_fwd_in(const ru3d_tensor* x, const void* w_packed, co
 extern "C" int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* res,
                                  const ru3d_tensor* dx, int k, int stride, int dtype, void* ws, size_t ws_bytes,
                                  void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_dgrad_f16(dy, w_packed, res, dx, k, stride, dtype, ws, ws_bytes, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(dy) && tensor_ok(dx) && w_packed, "conv3d_dgrad: bad tensor/weight");
     RU3D_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "conv3d_dgrad: k=%d stride=%d unsupported", k, stride);
@@ -286,6 +301,7 @@ static bool wgrad_shapes_ok(const ru3d_tensor* x, const ru3d_tensor* dy, int k, 
 
 extern "C" size_t ru3d_conv3d_wgrad_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* dy, int k, int stride,
                                                     int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_wgrad_workspace_bytes_f16(x, dy, k, stride, dtype));
     if (!wgrad_shapes_ok(x, dy, k, stride)) return 0;
     WgradGeom g = make_wgrad(x, dy, k, stride);
     if (stem_wgrad_eligible(g)) return stem_wgrad_ws_bytes(g);
@@ -296,6 +312,7 @@ extern "C" size_t ru3d_conv3d_wgrad_workspace_bytes(const ru3d_tensor* x, const 
 
 extern "C" int ru3d_conv3d_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, float* dw, void* ws, size_t ws_bytes,
                                  int k, int stride, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_wgrad_f16(x, dy, dw, ws, ws_bytes, k, stride, dtype, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "conv3d_wgrad: k=%d stride=%d unsupported", k, stride);
     RU3D_REQUIRE(wgrad_shapes_ok(x, dy, k, stride), "conv3d_wgrad: x/dy shape mismatch");
@@ -315,6 +332,7 @@ static bool convt_shapes_ok(const ru3d_tensor* x, const ru3d_tensor* y) {
 
 extern "C" int ru3d_convtranspose3d_k3s2p1_fwd(const ru3d_tensor* x, const void* w_packed, const float* bias,
                                                const ru3d_tensor* y, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_convtranspose3d_k3s2p1_fwd_f16(x, w_packed, bias, y, dtype, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(convt_shapes_ok(x, y) && w_packed, "convtranspose3d_fwd: y must have extents 2*x");
     RU3D_REQUIRE(dtype_ok(dtype), "convtranspose3d_fwd: bad dtype");
@@ -323,6 +341,7 @@ extern "C" int ru3d_convtranspose3d_k3s2p1_fwd(const ru3d_tensor* x, const void*
 
 extern "C" int ru3d_convtranspose3d_k3s2p1_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* dx,
                                                  int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_convtranspose3d_k3s2p1_dgrad_f16(dy, w_packed, dx, dtype, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(convt_shapes_ok(dx, dy) && w_packed, "convtranspose3d_dgrad: dy must have extents 2*dx");
     RU3D_REQUIRE(dtype_ok(dtype), "convtranspose3d_dgrad: bad dtype");
@@ -341,6 +360,7 @@ static WgradGeom make_convt_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy) {
 
 extern "C" size_t ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* dy,
                                                                     int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes_f16(x, dy, dtype));
     if (!convt_shapes_ok(x, dy)) return 0;
     WgradGeom g = make_convt_wgrad(x, dy);
     if (mfma_wgrad_eligible(g, dtype)) return wgrad_mfma_ws_bytes(g);
@@ -349,6 +369,7 @@ extern "C" size_t ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes(const ru3d_t
 
 extern "C" int ru3d_convtranspose3d_k3s2p1_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, float* dw, void* ws,
                                                  size_t ws_bytes, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_convtranspose3d_k3s2p1_wgrad_f16(x, dy, dw, ws, ws_bytes, dtype, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(convt_shapes_ok(x, dy), "convtranspose3d_wgrad: dy must have extents 2*x");
     RU3D_REQUIRE(dw && dtype_ok(dtype), "convtranspose3d_wgrad: bad argument");
@@ -356,3 +377,5 @@ extern "C" int ru3d_convtranspose3d_k3s2p1_wgrad(const ru3d_tensor* x, const ru3
     if (mfma_wgrad_eligible(g, dtype)) return wgrad_mfma_launch(dy->ptr, x->ptr, dw, ws, ws_bytes, g, as_stream(stream));
     return wgrad_generic_launch(dy->ptr, x->ptr, dw, ws, ws_bytes, g, dtype, as_stream(stream));
 }
+
+}  // namespace RU3D_NS

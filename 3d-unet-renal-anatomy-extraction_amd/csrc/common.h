@@ -4,11 +4,35 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include "f16_names.h"
 #include "../../include/ru3d.h"
 
+// The 16-bit storage element of this build.  The kernel sources are compiled twice into libru3d.so: once with bfloat16
+// (RU3D_BF16) and once, with -DRU3D_STORAGE_F16, with IEEE half (RU3D_F16: the reference's apex-O1 arithmetic,
+// trainer.py:538-542); `bf16` names whichever it is, and RU3D_BF16 stands for "this build's 16-bit dtype code".
+#ifdef RU3D_STORAGE_F16
+typedef _Float16 bf16;
+#define RU3D_BF16 RU3D_F16
+#define RU3D_NS ru3d_f16
+#define RU3D_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define RU3D_MFMA_ASM "v_mfma_f32_32x32x16_f16"
+#define RU3D_FWD_F16(dt, call)
+#else
 typedef __bf16 bf16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+#define RU3D_NS ru3d_bf16
+#define RU3D_MFMA_32X32X16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define RU3D_MFMA_ASM "v_mfma_f32_32x32x16_bf16"
+#define RU3D_DECL_F16(name) extern "C" decltype(name) name##_f16;
+RU3D_F16_APIS(RU3D_DECL_F16)
+#define RU3D_FWD_F16(dt, call) \
+    if ((dt) == RU3D_F16) return call
+#endif
+typedef __attribute__((ext_vector_type(8))) bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short i16x4;
+typedef __attribute__((address_space(3))) i16x4 lds_i16x4;
+// ds_read_b64_tr_b16: the 16-bit transposed LDS read is type-agnostic; the i16 form serves both storage types
+#define RU3D_DS_READ_TR16(p) __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_i16x4*)(p)))
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 

@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 
+namespace RU3D_NS {
+
 struct ConvGeom {
     int N;
     int Di, Hi, Wi, Cin, ldx;    // input tensor (of the data-movement form, not of the nn.Module)
@@ -108,3 +110,6 @@ bool head_wgrad_eligible(const WgradGeom& g, int dtype);
 size_t head_wgrad_ws_bytes(const WgradGeom& g);
 int head_wgrad_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, const WgradGeom& g,
                       int dtype, hipStream_t st);
+
+}  // namespace RU3D_NS
+using namespace RU3D_NS;

@@ -11,6 +11,8 @@
 #include "common.h"
 #include "conv.h"
 
+namespace RU3D_NS {
+
 template <typename T, typename TO, int CO_T, int VEC, bool TRANSPOSED>
 __global__ __launch_bounds__(256) void conv_generic_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                            const float* __restrict__ bias,
@@ -536,3 +538,5 @@ int wgrad_generic_launch(const void* x, const void* dy, float* dw, void* ws, siz
     if (rc) return rc;
     return wgrad_reduce_launch((const float*)ws, dw, chunks, g.taps, g.Cin, g.Cout, g.s_o, g.s_i, st);
 }
+
+}  // namespace RU3D_NS

@@ -14,6 +14,8 @@
 #include "common.h"
 #include "conv.h"
 
+namespace RU3D_NS {
+
 #define MF_PITCH 40  // bf16 elements per staged voxel (32 data + 8 pad) = 80 bytes
 
 // ---------------------------------------------------------------------------------------------------------
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
             for (int t = 0; t < NT; t++)
 #pragma unroll
                 for (int m = 0; m < MT; m++)
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s % WD][t], xq[s % XD][m], acc[m][t], 0, 0, 0);
+                    acc[m][t] = RU3D_MFMA_32X32X16(wq[s % WD][t], xq[s % XD][m], acc[m][t], 0, 0, 0);
             if (s + XD < S) {
                 const int tap1 = (s + XD) >> 1, kc1 = (s + XD) & 1;
                 const int toff1 = (((tap1 / 9) * HH + (tap1 / 3) % 3) * WW + tap1 % 3) * MF_PITCH;
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void conv3_s1_pc_kernel(MfmaConvArgs a) {
                 for (int t = 0; t < NT; t++)
 #pragma unroll
                     for (int m = 0; m < MT; m++)
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[s % WD][t], xq[s % XD][m], acc[m][t], 0, 0, 0);
+                        acc[m][t] = RU3D_MFMA_32X32X16(wq[s % WD][t], xq[s % XD][m], acc[m][t], 0, 0, 0);
                 if (s + XD < S) {
                     const int tap1 = (s + XD) >> 1, kc1 = (s + XD) & 1;
                     const int toff1 = ((tap1 / 9) * HH + (tap1 / 3) % 3) * WW + tap1 % 3;
@@ -871,7 +873,7 @@ __global__ __launch_bounds__(256) void conv_direct_mfma_kernel(DirectArgs a) {
 #pragma unroll
                         for (int t = 0; t < NT; t++) {
                             const bf16x8 wa = wrow[((int64_t)ks * NTT + t) * 64];
-                            acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, xb, acc[m][t], 0, 0, 0);
+                            acc[m][t] = RU3D_MFMA_32X32X16(wa, xb, acc[m][t], 0, 0, 0);
                         }
                     }
                 }
@@ -988,7 +990,7 @@ __global__ __launch_bounds__(256) void conv_gather_mfma_kernel(DirectArgs a) {
         for (int t = 0; t < NT; t++)
 #pragma unroll
             for (int m = 0; m < 2; m++)
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[t], xb[m], acc[m][t], 0, 0, 0);
+                acc[m][t] = RU3D_MFMA_32X32X16(wa[t], xb[m], acc[m][t], 0, 0, 0);
     };
     {
         bf16x8 x0[2], x1[2], w0[NT], w1[NT];
@@ -1142,14 +1144,14 @@ __global__ __launch_bounds__(256) void conv_direct_ksplit_kernel(DirectArgs a) {
         for (; j + 1 < j_hi; j += 2) {
             fetch(j + 1, xb1, wa1);
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa0[t], xb0, acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; t++) acc[t] = RU3D_MFMA_32X32X16(wa0[t], xb0, acc[t], 0, 0, 0);
             if (j + 2 < j_hi) fetch(j + 2, xb0, wa0);
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa1[t], xb1, acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; t++) acc[t] = RU3D_MFMA_32X32X16(wa1[t], xb1, acc[t], 0, 0, 0);
         }
         if (j < j_hi) {
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa0[t], xb0, acc[t], 0, 0, 0);
+            for (int t = 0; t < NT; t++) acc[t] = RU3D_MFMA_32X32X16(wa0[t], xb0, acc[t], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -1307,7 +1309,7 @@ __global__ __launch_bounds__(256, 2) void convt_tile_mfma_kernel(DirectArgs a) {
             for (int m = 0; m < MT; m++)
 #pragma unroll
                 for (int tt = 0; tt < NT; tt++)
-                    acc[m][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[tt], xb[m], acc[m][tt], 0, 0, 0);
+                    acc[m][tt] = RU3D_MFMA_32X32X16(wa[tt], xb[m], acc[m][tt], 0, 0, 0);
         };
         {
             bf16x8 w0[NT], w1[NT];
@@ -1504,8 +1506,8 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 __device__ __forceinline__ bf16x8 tr_frag(const bf16* p) {
     // 8 consecutive K (positions) of this lane's channel: two 4-row transposed reads
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * 32));
+    const bf16x4 lo = RU3D_DS_READ_TR16(p);
+    const bf16x4 hi = RU3D_DS_READ_TR16(p + 4 * 32);
     bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return r;
 }
@@ -1617,7 +1619,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_s1_mfma_kernel(MfmaWgradArgs a)
 #pragma unroll
             for (int t = 0; t < 7; t++) {   // tap 27 (wave 3, t = 6) recomputes tap 26 and is dropped: no branches here
                 const bf16x8 afrag = tr_frag(xs + hvb * 32 + toff[t] + lane_off);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[t], 0, 0, 0);
+                acc[t] = RU3D_MFMA_32X32X16(afrag, bfrag, acc[t], 0, 0, 0);
             }
         }
         __syncthreads();   // every wave is done with this tile's rows
@@ -1732,7 +1734,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_staged_mfma_kernel(StagedWgradAr
                     // tap 27 (wave 3, t = 6) recomputes tap 26 and is dropped at the end: no branches between MFMAs
                     const int tap = wave + 4 * t < 27 ? wave + 4 * t : 26;
                     const bf16x8 afrag = tr_frag(xs + (tap * PT + f0) * 32 + lane_off);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[t], 0, 0, 0);
+                    acc[t] = RU3D_MFMA_32X32X16(afrag, bfrag, acc[t], 0, 0, 0);
                 }
             }
         } else {
@@ -1741,7 +1743,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_staged_mfma_kernel(StagedWgradAr
                 const int f0 = (wave * (PT / 64) + kk) * 16 + 8 * h;
                 const bf16x8 bfrag = tr_frag(ds + f0 * 32 + lane_off);
                 const bf16x8 afrag = tr_frag(xs + f0 * 32 + lane_off);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc[0], 0, 0, 0);
+                acc[0] = RU3D_MFMA_32X32X16(afrag, bfrag, acc[0], 0, 0, 0);
             }
         }
     }
@@ -1876,3 +1878,5 @@ int wgrad_mfma_launch(const void* x, const void* dy, float* dw, void* ws, size_t
     if (rc) return rc;
     return wgrad_reduce_launch((const float*)ws, dw, a.G, 27, g.Cin, g.Cout, g.s_o, g.s_i, st);
 }
+
+}  // namespace RU3D_NS

@@ -24,6 +24,8 @@
 
 #include <type_traits>
 
+namespace RU3D_NS {
+
 namespace {
 constexpr int TH = 8, TW = 32, HH = TH + 2, WW = TW + 2;
 constexpr int PROWS = HH * WW;        // 340 halo rows per plane
@@ -71,11 +73,11 @@ template <bool WA, bool ZERO>
 __device__ __forceinline__ void mfma_w(f32x16& acc, const bf16x8& w, const bf16x8& x) {
     const i32x4 wi = __builtin_bit_cast(i32x4, w), xi = __builtin_bit_cast(i32x4, x);
     if constexpr (ZERO) {
-        if constexpr (WA) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "a"(wi), "v"(xi));
-        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc) : "v"(wi), "v"(xi));
+        if constexpr (WA) asm volatile(RU3D_MFMA_ASM " %0, %1, %2, 0" : "=a"(acc) : "a"(wi), "v"(xi));
+        else asm volatile(RU3D_MFMA_ASM " %0, %1, %2, 0" : "=a"(acc) : "v"(wi), "v"(xi));
     } else {
-        if constexpr (WA) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(wi), "v"(xi));
-        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(wi), "v"(xi));
+        if constexpr (WA) asm volatile(RU3D_MFMA_ASM " %0, %1, %2, %0" : "+a"(acc) : "a"(wi), "v"(xi));
+        else asm volatile(RU3D_MFMA_ASM " %0, %1, %2, %0" : "+a"(acc) : "v"(wi), "v"(xi));
     }
 }
 constexpr int WA_FRAGS = 48;          // weight fragments held in AGPRs (48 x 4 + 64 accumulator registers = 256)
@@ -444,3 +446,5 @@ int conv_slide_launch(const void* x, const void* w, const float* bias, const voi
     else hipLaunchKernelGGL((conv3_s1_slide32_kernel<false, false>), dim3(p.grid, p.ny), dim3(256), 0, st, a);
     return ru3d_check_launch("conv3_s1_slide32");
 }
+
+}  // namespace RU3D_NS

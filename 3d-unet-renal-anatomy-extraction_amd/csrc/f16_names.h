@@ -1,0 +1,54 @@
+// Two builds of the same kernel sources share libru3d.so: the bf16 build owns the public C ABI names and forwards
+// calls whose storage dtype is RU3D_F16 to the fp16 build (compiled with -DRU3D_STORAGE_F16), whose entry points carry
+// the suffix _f16.  This header renames them there (before ru3d.h declares them) and declares them here.
+#pragma once
+#define RU3D_F16_APIS(X) \
+    X(ru3d_packed_weight_bytes) \
+    X(ru3d_pack_weight) \
+    X(ru3d_pack_weights) \
+    X(ru3d_conv3d_workspace_bytes) \
+    X(ru3d_conv3d_fwd) \
+    X(ru3d_conv3d_fwd_in_workspace_bytes) \
+    X(ru3d_conv3d_fwd_in) \
+    X(ru3d_conv3d_dgrad) \
+    X(ru3d_conv3d_wgrad_workspace_bytes) \
+    X(ru3d_conv3d_wgrad) \
+    X(ru3d_convtranspose3d_k3s2p1_fwd) \
+    X(ru3d_convtranspose3d_k3s2p1_dgrad) \
+    X(ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes) \
+    X(ru3d_convtranspose3d_k3s2p1_wgrad) \
+    X(ru3d_instnorm_stats) \
+    X(ru3d_in_lrelu_fwd) \
+    X(ru3d_in_lrelu_bwd) \
+    X(ru3d_channel_sum) \
+    X(ru3d_copy_channels) \
+    X(ru3d_add) \
+    X(ru3d_cast_f32) \
+    X(ru3d_ncdhw_to_ndhwc) \
+    X(ru3d_ndhwc_to_ncdhw)
+
+#ifdef RU3D_STORAGE_F16
+#define ru3d_packed_weight_bytes ru3d_packed_weight_bytes_f16
+#define ru3d_pack_weight ru3d_pack_weight_f16
+#define ru3d_pack_weights ru3d_pack_weights_f16
+#define ru3d_conv3d_workspace_bytes ru3d_conv3d_workspace_bytes_f16
+#define ru3d_conv3d_fwd ru3d_conv3d_fwd_f16
+#define ru3d_conv3d_fwd_in_workspace_bytes ru3d_conv3d_fwd_in_workspace_bytes_f16
+#define ru3d_conv3d_fwd_in ru3d_conv3d_fwd_in_f16
+#define ru3d_conv3d_dgrad ru3d_conv3d_dgrad_f16
+#define ru3d_conv3d_wgrad_workspace_bytes ru3d_conv3d_wgrad_workspace_bytes_f16
+#define ru3d_conv3d_wgrad ru3d_conv3d_wgrad_f16
+#define ru3d_convtranspose3d_k3s2p1_fwd ru3d_convtranspose3d_k3s2p1_fwd_f16
+#define ru3d_convtranspose3d_k3s2p1_dgrad ru3d_convtranspose3d_k3s2p1_dgrad_f16
+#define ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes_f16
+#define ru3d_convtranspose3d_k3s2p1_wgrad ru3d_convtranspose3d_k3s2p1_wgrad_f16
+#define ru3d_instnorm_stats ru3d_instnorm_stats_f16
+#define ru3d_in_lrelu_fwd ru3d_in_lrelu_fwd_f16
+#define ru3d_in_lrelu_bwd ru3d_in_lrelu_bwd_f16
+#define ru3d_channel_sum ru3d_channel_sum_f16
+#define ru3d_copy_channels ru3d_copy_channels_f16
+#define ru3d_add ru3d_add_f16
+#define ru3d_cast_f32 ru3d_cast_f32_f16
+#define ru3d_ncdhw_to_ndhwc ru3d_ncdhw_to_ndhwc_f16
+#define ru3d_ndhwc_to_ncdhw ru3d_ndhwc_to_ncdhw_f16
+#endif

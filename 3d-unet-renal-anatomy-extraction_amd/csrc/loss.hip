@@ -469,3 +469,50 @@ extern "C" int ru3d_adam_multi(const ru3d_adam_tensor* tensors, const int32_t* b
                        chunk_elems, lr, beta1, beta2, eps, bias_corr1, sqrtf(bias_corr2), grad_scale);
     return ru3d_check_launch("adam_multi");
 }
+
+// --------------------------------------------------------------------------- loss scaling (fp16 storage)
+// Dynamic loss scaling of the reference's mixed-precision mode (apex O1, trainer.py:492-493, 538-542): gradients are
+// computed on `scale * loss`; before the optimizer step every gradient is checked for inf / nan (an overflow skips the
+// step and halves the scale) and multiplied by 1 / scale.  Same table / block-map layout as ru3d_adam_multi; only the
+// `grad` and `count` fields are read.  scale == 1 checks without writing.
+__global__ __launch_bounds__(256) void grad_scale_check_kernel(const ru3d_adam_tensor* __restrict__ tensors,
+                                                               const int32_t* __restrict__ block_map, int chunk_elems,
+                                                               float scale, float* __restrict__ found_inf) {
+    const ru3d_adam_tensor t = tensors[block_map[2 * blockIdx.x]];
+    if (!t.grad) return;
+    float* g = const_cast<float*>(t.grad);
+    const int64_t begin = (int64_t)block_map[2 * blockIdx.x + 1] * chunk_elems;
+    int64_t end = begin + chunk_elems;
+    if (end > t.count) end = t.count;
+    const bool write = scale != 1.f;
+    bool bad = false;
+    int64_t i = begin + (int64_t)threadIdx.x * 4;
+    if ((((uintptr_t)g) & 15) == 0) {
+        for (; i + 3 < end; i += 1024) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(g + i);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                bad = bad || !(fabsf(v[k]) <= 3.402823466e38f);   // false for inf and nan
+                v[k] *= scale;
+            }
+            if (write) *reinterpret_cast<f32x4*>(g + i) = v;
+        }
+    }
+    for (; i < end; i += 1024)
+        for (int k = 0; k < 4 && i + k < end; k++) {
+            const float v = g[i + k];
+            bad = bad || !(fabsf(v) <= 3.402823466e38f);
+            if (write) g[i + k] = v * scale;
+        }
+    if (__any(bad) && (threadIdx.x & 63) == 0) *found_inf = 1.f;   // every writer stores the same value
+}
+
+extern "C" int ru3d_grad_scale_check(const ru3d_adam_tensor* tensors, const int32_t* block_map, int nblocks,
+                                     int chunk_elems, float scale, float* found_inf, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(tensors && block_map && found_inf && nblocks > 0 && chunk_elems >= 1024 && (chunk_elems % 1024) == 0,
+                 "grad_scale_check: bad argument (chunk_elems must be a positive multiple of 1024)");
+    hipLaunchKernelGGL(grad_scale_check_kernel, dim3((unsigned)nblocks), dim3(256), 0, as_stream(stream), tensors,
+                       block_map, chunk_elems, scale, found_inf);
+    return ru3d_check_launch("grad_scale_check");
+}

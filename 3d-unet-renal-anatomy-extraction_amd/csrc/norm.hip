@@ -9,6 +9,8 @@
 #include "common.h"
 #include <initializer_list>
 
+namespace RU3D_NS {
+
 struct ChanLoop {
     int V;      // voxels per sample
     int G;      // channel groups (C / VEC)
@@ -396,7 +398,9 @@ static size_t reduce_ws_bytes(const ru3d_tensor* t) {
     return (size_t)t->n * chunks * t->c * 2 * sizeof(double) + (size_t)t->n * t->c * 2 * sizeof(float) + 256;
 }
 
+#ifndef RU3D_STORAGE_F16
 extern "C" size_t ru3d_reduce_workspace_bytes(const ru3d_tensor* t) { return t ? reduce_ws_bytes(t) : 0; }
+#endif
 
 template <typename T>
 static int stats_impl(const ru3d_tensor* y, const float* drop, float* mean, float* scale, void* ws, float eps,
@@ -421,6 +425,7 @@ static int stats_impl(const ru3d_tensor* y, const float* drop, float* mean, floa
 
 extern "C" int ru3d_instnorm_stats(const ru3d_tensor* y, const float* drop_scale, float* mean, float* scale, void* ws,
                                    size_t ws_bytes, float eps, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_instnorm_stats_f16(y, drop_scale, mean, scale, ws, ws_bytes, eps, dtype, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(y), "instnorm_stats: bad tensor");
     RU3D_REQUIRE(mean && scale && ws, "instnorm_stats: null output/workspace");
@@ -453,6 +458,7 @@ static int in_fwd_impl(const ru3d_tensor* y, const float* mean, const float* sca
 
 extern "C" int ru3d_in_lrelu_fwd(const ru3d_tensor* y, const float* mean, const float* scale, const ru3d_tensor* res,
                                  const ru3d_tensor* out, float slope, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_in_lrelu_fwd_f16(y, mean, scale, res, out, slope, dtype, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(y) && tensor_ok(out) && same_shape(y, out), "in_lrelu_fwd: bad y/out");
     RU3D_REQUIRE(!res || (tensor_ok(res) && same_shape(y, res)), "in_lrelu_fwd: bad residual");
@@ -518,6 +524,7 @@ extern "C" int ru3d_in_lrelu_bwd(const ru3d_tensor* gout, const ru3d_tensor* out
                                  const float* mean, const float* scale, const ru3d_tensor* dy,
                                  const ru3d_tensor* gpre, void* ws, size_t ws_bytes, float slope, int zero_far,
                                  float* gpre_sum, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_in_lrelu_bwd_f16(gout, out, y, mean, scale, dy, gpre, ws, ws_bytes, slope, zero_far, gpre_sum, dtype, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(!gpre_sum || gpre, "in_lrelu_bwd: gpre_sum needs the residual form (gpre != NULL)");
     RU3D_REQUIRE(tensor_ok(gout) && tensor_ok(out) && tensor_ok(y) && tensor_ok(dy), "in_lrelu_bwd: bad tensor");
@@ -555,6 +562,7 @@ static int chansum_impl(const ru3d_tensor* t, float* out, void* ws, hipStream_t 
 
 extern "C" int ru3d_channel_sum(const ru3d_tensor* t, float* out, void* ws, size_t ws_bytes, int dtype,
                                 void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_channel_sum_f16(t, out, ws, ws_bytes, dtype, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(t) && out && ws, "channel_sum: bad argument");
     RU3D_REQUIRE(ws_bytes >= reduce_ws_bytes(t), "channel_sum: workspace too small");
@@ -583,6 +591,7 @@ static int copy_add_impl(const ru3d_tensor* a, const ru3d_tensor* b, const ru3d_
 }
 
 extern "C" int ru3d_copy_channels(const ru3d_tensor* src, const ru3d_tensor* dst, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_copy_channels_f16(src, dst, dtype, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(src) && tensor_ok(dst) && same_shape(src, dst), "copy_channels: bad tensors");
     RU3D_REQUIRE((int64_t)src->d * src->h * src->w < (1ll << 31), "copy_channels: sample too large");
@@ -593,6 +602,7 @@ extern "C" int ru3d_copy_channels(const ru3d_tensor* src, const ru3d_tensor* dst
 
 extern "C" int ru3d_add(const ru3d_tensor* a, const ru3d_tensor* b, const ru3d_tensor* dst, int dtype,
                         void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_add_f16(a, b, dst, dtype, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(a) && tensor_ok(b) && tensor_ok(dst) && same_shape(a, b) && same_shape(a, dst),
                  "add: bad tensors");
@@ -615,6 +625,7 @@ __global__ void cast_f32_kernel(const float* __restrict__ src, int lds, T* __res
 }
 
 extern "C" int ru3d_cast_f32(const ru3d_tensor* src, const ru3d_tensor* dst, int dst_dtype, void* stream) {
+    RU3D_FWD_F16(dst_dtype, ru3d_cast_f32_f16(src, dst, dst_dtype, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(tensor_ok(src) && tensor_ok(dst) && same_shape(src, dst), "cast_f32: bad tensors");
     const int64_t rows = nvox(src);
@@ -647,6 +658,7 @@ __global__ void dropout_scale_kernel(float* __restrict__ scale, int count, float
     scale[i] = (u >= p) ? 1.0f / (1.0f - p) : 0.0f;
 }
 
+#ifndef RU3D_STORAGE_F16
 extern "C" int ru3d_dropout3d_scale(float* scale, int count, float p, uint64_t seed, uint64_t offset,
                                     void* stream) {
     Ru3dDeviceGuard dev_guard(stream);
@@ -655,6 +667,7 @@ extern "C" int ru3d_dropout3d_scale(float* scale, int count, float p, uint64_t s
                        p, seed, offset);
     return ru3d_check_launch("dropout3d_scale");
 }
+#endif
 
 // --------------------------------------------------------------------------- NCDHW <-> NDHWC
 // Tiled transpose through LDS: [C][V] <-> [V][C] per sample; 32x32 tiles, padded rows.
@@ -695,6 +708,7 @@ __global__ __launch_bounds__(256) void repack_kernel(const float* __restrict__ n
 }
 
 extern "C" int ru3d_ncdhw_to_ndhwc(const float* src, const ru3d_tensor* dst, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_ncdhw_to_ndhwc_f16(src, dst, dtype, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(src && tensor_ok(dst), "ncdhw_to_ndhwc: bad argument");
     const int64_t V = (int64_t)dst->d * dst->h * dst->w;
@@ -711,6 +725,7 @@ extern "C" int ru3d_ncdhw_to_ndhwc(const float* src, const ru3d_tensor* dst, int
 }
 
 extern "C" int ru3d_ndhwc_to_ncdhw(const ru3d_tensor* src, float* dst, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_ndhwc_to_ncdhw_f16(src, dst, dtype, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(dst && tensor_ok(src), "ndhwc_to_ncdhw: bad argument");
     const int64_t V = (int64_t)src->d * src->h * src->w;
@@ -725,3 +740,5 @@ extern "C" int ru3d_ndhwc_to_ncdhw(const ru3d_tensor* src, float* dst, int dtype
         return ru3d_fail(-1, "ndhwc_to_ncdhw: bad dtype %d", dtype);
     return ru3d_check_launch("ndhwc_to_ncdhw");
 }
+
+}  // namespace RU3D_NS

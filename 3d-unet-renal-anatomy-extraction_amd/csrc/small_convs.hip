@@ -6,6 +6,8 @@
 #include "common.h"
 #include "conv.h"
 
+namespace RU3D_NS {
+
 // --------------------------------------------------------------------------- stem forward (Cin == 1)
 // thread = (voxel, group of 8 couts): 27 scalar x loads (neighbouring lanes share them through L1), 27x8 FMA,
 // one 16-byte (bf16) / 32-byte (f32) store; consecutive lanes write consecutive channel groups of consecutive
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const bf16* __restri
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
                 const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(&pm[f * 40 + ks * 16 + 8 * h]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag[ks], bfrag, acc, 0, 0, 0);
+                acc = RU3D_MFMA_32X32X16(afrag[ks], bfrag, acc, 0, 0, 0);
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -377,8 +379,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const T* __restrict__ x
 #define STEM_MF_BLOCKS 1024
 typedef __attribute__((address_space(3))) bf16x4 stem_lds_bf16x4;
 __device__ __forceinline__ bf16x8 stem_tr_frag(const bf16* p) {
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((stem_lds_bf16x4*)p);
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((stem_lds_bf16x4*)(p + 4 * 32));
+    const bf16x4 lo = RU3D_DS_READ_TR16(p);
+    const bf16x4 hi = RU3D_DS_READ_TR16(p + 4 * 32);
     bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return r;
 }
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const bf16* __rest
             const int ks = wave * 4 + j;
             const bf16x8 afrag = *reinterpret_cast<const bf16x8*>(&xs[abase + (tap < 27 ? ((ks >> 1) * 32 + (ks & 1) * 16) : 0)]);
             const bf16x8 bfrag = stem_tr_frag(ds + (ks * 16 + 8 * h) * 32 + lane_off);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag, acc, 0, 0, 0);
+            acc = RU3D_MFMA_32X32X16(afrag, bfrag, acc, 0, 0, 0);
         }
     }
     // sum the 4 waves' partial tiles in a fixed order; D row = tap = (i & 3) + 8 (i >> 2) + 4 (lane >> 5), col = co
@@ -588,3 +590,5 @@ int head_wgrad_launch(const void* x, const void* dy, float* dw, void* ws, size_t
     if (rc) return rc;
     return wgrad_reduce_launch((const float*)ws, dw, chunks, 1, g.Cin, g.Cout, g.s_o, g.s_i, st);
 }
+
+}  // namespace RU3D_NS

@@ -10,6 +10,8 @@
 #include "common.h"
 #include "conv.h"
 
+namespace RU3D_NS {
+
 namespace {
 constexpr int TDO = 2, THO = 2, TWO = 32;                  // dense-operand (output-side) tile: 128 positions
 constexpr int LD = 2 * TDO + 1, LH = 2 * THO + 1, LW = 2 * TWO + 1;   // 5 x 5 lines of 65 gathered rows
@@ -31,8 +33,8 @@ struct WS2Args {
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 __device__ __forceinline__ bf16x8 tr_frag(const bf16* p) {
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * 32));
+    const bf16x4 lo = RU3D_DS_READ_TR16(p);
+    const bf16x4 hi = RU3D_DS_READ_TR16(p + 4 * 32);
     bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return r;
 }
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s2_tile_kernel(WS2Args a) {
                 const bf16x8 afrag = tr_frag(xs + rowb * 32 + toff[t] + lane_off);
 #pragma unroll
                 for (int o = 0; o < NCO; o++)
-                    acc[t][o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[o], acc[t][o], 0, 0, 0);
+                    acc[t][o] = RU3D_MFMA_32X32X16(afrag, bfrag[o], acc[t][o], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);   // keep the k-steps apart: hoisting all 64 fragment reads spills
         }
@@ -213,3 +215,5 @@ int wgrad_s2_launch(const void* x, const void* dy, float* dw, void* ws, const Wg
     if (rc) return rc;
     return wgrad_reduce_launch((const float*)ws, dw, a.G, 27, g.Cin, g.Cout, g.s_o, g.s_i, st);
 }
+
+}  // namespace RU3D_NS

@@ -16,6 +16,8 @@
 
 #include <type_traits>
 
+namespace RU3D_NS {
+
 namespace {
 constexpr int TH = 8, TW = 32, HH = TH + 2, WW = TW + 2;
 constexpr int PROWS = HH * WW;        // 340 rows per X plane
@@ -37,8 +39,8 @@ struct WSlideArgs {
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 __device__ __forceinline__ bf16x8 tr_frag(const bf16* p) {
     // 8 consecutive K (positions) of this lane's channel: two 4-row transposed reads
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 4 * 32));
+    const bf16x4 lo = RU3D_DS_READ_TR16(p);
+    const bf16x4 hi = RU3D_DS_READ_TR16(p + 4 * 32);
     bf16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return r;
 }
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
                 if constexpr (ks + 2 < 16) fetch(std::integral_constant<int, ks + 2>{}, (ks + 2) % 3);
 #pragma unroll
                 for (int t = 0; t < 7; t++)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aq[ks % 3][t], bq[ks % 3], acc[t], 0, 0, 0);
+                    acc[t] = RU3D_MFMA_32X32X16(aq[ks % 3][t], bq[ks % 3], acc[t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             });
             __syncthreads();
@@ -275,3 +277,5 @@ int wgrad_slide_launch(const void* x, const void* dy, float* dw, void* ws, const
     if (rc) return rc;
     return wgrad_reduce_launch((const float*)ws, dw, p.G, 27, g.Cin, g.Cout, g.s_o, g.s_i, st);
 }
+
+}  // namespace RU3D_NS

@@ -16,7 +16,8 @@ Out-of-hot-path variants (ConvBlock*, RecBlock, ResRecBlock, AttBlock, MaxPoolBl
 attention configurations: reference 153-295, 353-371, 452-463) are ordinary torch modules.
 
 Precision: `set_compute_dtype(model, torch.bfloat16)` (or env RU3D_DTYPE=bf16) selects bf16 storage
-with fp32 accumulation; the default float32 is the parity mode.  Logits are always fp32.
+with fp32 accumulation, torch.float16 the reference's apex-O1 arithmetic (fp16 storage, fp32 accumulation; train it
+with optim.LossScaler / Trainer.fit(use_amp=True)); the default float32 is the parity mode.  Logits are always fp32.
 """
 import os
 
@@ -27,10 +28,11 @@ import _native as N
 import _ops as ops
 
 _DEFAULT_DTYPE = {"fp32": torch.float32, "float32": torch.float32, "bf16": torch.bfloat16,
-                  "bfloat16": torch.bfloat16}[os.environ.get("RU3D_DTYPE", "fp32").lower()]
+                  "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16,
+                  "half": torch.float16}[os.environ.get("RU3D_DTYPE", "fp32").lower()]
 
 
-_STORAGE_DTYPES = (torch.float32, torch.bfloat16)
+_STORAGE_DTYPES = (torch.float32, torch.bfloat16, torch.float16)
 
 
 def set_compute_dtype(model, dtype):
@@ -413,7 +415,10 @@ class Unet(nn.Module):
         if chain is not None:
             for blk in chain:
                 widths += [blk.in_channels, blk.out_channels]
+        # worth it while the padding adds at most half again to every width (F >= 22); narrower toy models keep the
+        # direct kernels rather than carry 2-4x the activation bytes
         pad = (chain is not None and self.compute_dtype != torch.float32 and any(c % 32 for c in widths)
+               and all(ops.cpad(c) * 2 <= 3 * c for c in widths)
                and os.environ.get("RU3D_PAD_CHANNELS", "1") != "0")
         self._pad = pad
         for blk in (chain or []):

@@ -53,7 +53,8 @@ class Adam(torch.optim.Optimizer):
         return plan
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_scale=1.0):
+        """grad_scale: factor applied to every gradient inside the update kernel (1 / loss_scale in fp16 mode)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -99,8 +100,126 @@ class Adam(torch.optim.Optimizer):
             bc1 = 1.0 - b1 ** step_no
             bc2 = 1.0 - b2 ** step_no
             check(N.lib.ru3d_adam_multi(ptr(plan["table"]), ptr(plan["block_map"]), plan["nblocks"], _CHUNK,
-                                        float(group["lr"]), float(b1), float(b2), float(group["eps"]), bc1, bc2, 1.0,
-                                        stream()), "adam_multi")
+                                        float(group["lr"]), float(b1), float(b2), float(group["eps"]), bc1, bc2,
+                                        float(grad_scale), stream()), "adam_multi")
         import _ops
         _ops.WEIGHTS_EPOCH[0] += 1      # packed copies of the weights are stale now
         return loss
+
+
+class _GradTable:
+    """Device table of (grad pointer, count) per parameter in ru3d_adam_tensor layout + block map, rebuilt when the
+    gradient tensors move (GradSync re-aliases them into its buckets; autograd allocates fresh ones otherwise)."""
+
+    def __init__(self):
+        self.key = None
+        self.table = self.block_map = None
+        self.nblocks = 0
+        self.host = None
+        self.copied = None
+
+    def update(self, params):
+        grads = [p.grad for p in params]
+        dev = next(g.device for g in grads if g is not None)
+        key = tuple((0 if g is None else g.data_ptr(), p.numel()) for p, g in zip(params, grads))
+        if key == self.key:
+            return
+        if self.copied is not None:
+            self.copied.synchronize()
+        n = len(params)
+        if self.host is None or self.host.numel() != n * ctypes.sizeof(_AdamTensor):
+            self.host = torch.empty(n * ctypes.sizeof(_AdamTensor), dtype=torch.uint8).pin_memory()
+            self.table = torch.empty(self.host.numel(), dtype=torch.uint8, device=dev)
+            blocks = []
+            for ti, p in enumerate(params):
+                for c in range((p.numel() + _CHUNK - 1) // _CHUNK):
+                    blocks += [ti, c]
+            self.block_map = torch.tensor(blocks, dtype=torch.int32).to(dev)
+            self.nblocks = len(blocks) // 2
+        arr = (_AdamTensor * n).from_buffer(self.host.numpy())
+        for i, (p, g) in enumerate(zip(params, grads)):
+            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
+                raise N.Ru3dError("LossScaler: gradients must be contiguous float32")
+            arr[i] = _AdamTensor(None, None if g is None else g.data_ptr(), None, None, p.numel())
+        self.table.copy_(self.host, non_blocking=True)
+        self.copied = torch.cuda.Event()
+        self.copied.record()
+        self.key = key
+
+
+class LossScaler:
+    """Dynamic loss scaling for fp16 storage - the reference's apex O1 behaviour (trainer.py:492-493 `amp.scale_loss`,
+    538-542 `amp.initialize(..., opt_level)`): start at 2**16, skip the optimizer step and halve the scale when a
+    gradient overflows, double it after `growth_interval` (2000) clean steps.
+
+        scaler = optim.LossScaler()
+        scaler.scale(loss).backward()
+        scaler.step(optimizer)        # unscale + inf/nan check on the device, one 4-byte read-back, step or skip
+
+    With optim.Adam the 1/scale factor is applied inside the fused update kernel; any other torch optimizer gets its
+    gradients unscaled in place first.  bf16 storage needs none of this."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000,
+                 min_scale=2.0 ** -24):
+        self.loss_scale = float(init_scale)
+        self.growth_factor, self.backoff_factor = float(growth_factor), float(backoff_factor)
+        self.growth_interval = int(growth_interval)
+        self.min_scale = float(min_scale)
+        self.growth_tracker = 0
+        self.skipped_steps = 0
+        self._scale_t = None
+        self._found = None
+        self._tables = {}
+
+    def scale(self, loss):
+        if self._scale_t is None or self._scale_t.device != loss.device:
+            self._scale_t = torch.full((), self.loss_scale, dtype=torch.float32, device=loss.device)
+            self._found = torch.zeros(1, dtype=torch.float32, device=loss.device)
+        return loss * self._scale_t
+
+    def step(self, optimizer):
+        """Returns True when the optimizer stepped, False when the step was skipped because of an overflow."""
+        if self._scale_t is None:
+            raise RuntimeError("LossScaler.step() before LossScaler.scale(loss).backward()")
+        fused = isinstance(optimizer, Adam)
+        inv = 1.0 / self.loss_scale
+        self._found.zero_()
+        any_grad = False
+        for gi, group in enumerate(optimizer.param_groups):
+            params = [p for p in group["params"]]
+            if not any(p.grad is not None for p in params):
+                continue
+            any_grad = True
+            tab = self._tables.setdefault((id(optimizer), gi), _GradTable())
+            tab.update(params)
+            N.note_device(tab.table.device)
+            check(N.lib.ru3d_grad_scale_check(ptr(tab.table), ptr(tab.block_map), tab.nblocks, _CHUNK,
+                                              1.0 if fused else inv, ptr(self._found), stream()), "grad_scale_check")
+        overflow = any_grad and bool(self._found.item() != 0.0)      # the one host read-back of the fp16 step
+        if overflow:
+            self.loss_scale = max(self.loss_scale * self.backoff_factor, self.min_scale)
+            self.growth_tracker = 0
+            self.skipped_steps += 1
+        else:
+            if fused:
+                optimizer.step(grad_scale=inv)
+            else:
+                optimizer.step()
+            self.growth_tracker += 1
+            if self.growth_tracker >= self.growth_interval:
+                self.loss_scale *= self.growth_factor
+                self.growth_tracker = 0
+        self._scale_t.fill_(self.loss_scale)
+        return not overflow
+
+    def state_dict(self):
+        return {"loss_scale": self.loss_scale, "growth_tracker": self.growth_tracker,
+                "skipped_steps": self.skipped_steps, "ru3d": "fp16"}
+
+    def load_state_dict(self, state):
+        if isinstance(state, dict) and "loss_scale" in state:
+            self.loss_scale = float(state["loss_scale"])
+            self.growth_tracker = int(state.get("growth_tracker", 0))
+            self.skipped_steps = int(state.get("skipped_steps", 0))
+            if self._scale_t is not None:
+                self._scale_t.fill_(self.loss_scale)

@@ -7,8 +7,9 @@ spelling the oldest script uses (reference run_train.py:71-96: `Trainer(criterio
 vd_transform=)`, `fit(dataset, batch_size=, epochs=, ...)`, `save` / `load`).
 
 What changes underneath:
-  * `use_amp=True` selects bf16 storage / fp32 accumulation of the native kernels (the reference
-    patched fp16 convs in through apex O1, trainer.py:538-542); no loss scaling is needed for bf16.
+  * `use_amp=True` selects 16-bit storage / fp32 accumulation of the native kernels: fp16 with dynamic loss
+    scaling for the reference's opt_level 'O1' (apex patched fp16 convs in, trainer.py:538-542, and scaled the
+    loss, :492-493), or bf16 without loss scaling for opt_level='bf16'.
   * per-step `.item()` calls are deferred: the loss/metric scalars stay on the device and are read
     back once per `sync_every` steps (default: every step, the reference's behaviour), so the GPU
     is not drained between kernels.  The NaN rule is the reference's: a NaN step is excluded from
@@ -111,6 +112,7 @@ class Trainer():
         self.progress = progress
         self.progress_bar = _NullBar()
         self._grad_sync = None
+        self._scaler = None
 
     # ------------------------------------------------------------------ small helpers
     def _split_indices(self):
@@ -177,10 +179,16 @@ class Trainer():
                 self.optimizer.zero_grad()
                 if self._grad_sync is not None:
                     self._grad_sync.begin_step()
-                loss.backward()
+                if self._scaler is not None:
+                    self._scaler.scale(loss).backward()      # reference: amp.scale_loss(loss, optimizer)
+                else:
+                    loss.backward()
                 if self._grad_sync is not None:
                     self._grad_sync.finish_step()
-                self.optimizer.step()
+                if self._scaler is not None:
+                    self._scaler.step(self.optimizer)        # skipped on overflow, like apex's patched step
+                else:
+                    self.optimizer.step()
             scalars = {'loss': loss}
             if self.metrics is not None:
                 with torch.no_grad():
@@ -303,9 +311,29 @@ class Trainer():
         self.use_amp = use_amp
         self.save_dir = save_dir
         if use_amp:
-            # apex O1 (fp16 convs) in the reference; here: bf16 storage + fp32 accumulate in the HIP kernels
+            # reference: amp.initialize(model, optimizer, opt_level=opt_level) - apex O1 patches fp16 convolutions in
+            # and scales the loss dynamically.  Here: opt_level 'O1' / 'O2' / 'O3' select fp16 storage with fp32
+            # accumulation in the HIP kernels plus optim.LossScaler (apex's schedule); opt_level 'bf16' (an extension,
+            # also RU3D_AMP_DTYPE=bf16) selects bf16 storage, which needs no loss scaling.
             import network
-            network.set_compute_dtype(self.model, torch.bfloat16)
+            import optim as optim_mod
+            level = str(opt_level).lower()
+            if level == 'o0':
+                amp_dtype = torch.float32
+            elif level in ('bf16', 'bfloat16') or os.environ.get('RU3D_AMP_DTYPE', '').lower() in ('bf16', 'bfloat16'):
+                amp_dtype = torch.bfloat16
+            elif level in ('o1', 'o2', 'o3', 'fp16', 'float16'):
+                amp_dtype = torch.float16
+            else:
+                raise ValueError("Trainer.fit: unknown opt_level %r" % (opt_level,))
+            network.set_compute_dtype(self.model, amp_dtype)
+            if amp_dtype == torch.float16:
+                if self._scaler is None:
+                    self._scaler = optim_mod.LossScaler()
+                    if isinstance(self.amp_state_dict, dict):
+                        self._scaler.load_state_dict(self.amp_state_dict)
+            else:
+                self._scaler = None
         if _dist_ready():
             self._enter_distributed()
         self.progress_bar = tqdm(total=0) if (tqdm is not None and self.progress) else _NullBar()
@@ -347,8 +375,9 @@ class Trainer():
         if self.scheduler is not None:
             checkpoint['scheduler_state_dict'] = self.scheduler.state_dict()
         if self.use_amp:
-            # apex's loss-scaler state in the reference; bf16 needs none - kept so the key set matches
-            checkpoint['amp_state_dict'] = self.amp_state_dict or {'ru3d': 'bf16'}
+            # apex's loss-scaler state in the reference (trainer.py:617-618); bf16 needs none - the key is kept
+            checkpoint['amp_state_dict'] = (self._scaler.state_dict() if self._scaler is not None
+                                            else (self.amp_state_dict or {'ru3d': 'bf16'}))
         directory = os.path.dirname(file_path)
         if directory:
             os.makedirs(directory, exist_ok=True)
@@ -368,6 +397,8 @@ class Trainer():
         self.best_result = checkpoint['best_result']
         if 'amp_state_dict' in checkpoint:
             self.amp_state_dict = checkpoint['amp_state_dict']
+            if self._scaler is not None:
+                self._scaler.load_state_dict(self.amp_state_dict)
         if 'scheduler_state_dict' in checkpoint and self.scheduler is not None:
             self.scheduler.load_state_dict(checkpoint['scheduler_state_dict'])
 

@@ -33,8 +33,10 @@ extern "C" {
 
 #define RU3D_VERSION 200
 
-/* storage dtypes of activations / packed weights (accumulation is always fp32) */
-enum { RU3D_F32 = 0, RU3D_BF16 = 1 };
+/* storage dtypes of activations / packed weights (accumulation is always fp32).  RU3D_F16 is the reference's
+ * mixed-precision arithmetic (apex O1: fp16 convolutions with fp32 accumulation, trainer.py:492-493, 538-542) and
+ * needs loss scaling on the host side; RU3D_BF16 needs none.  A call uses ONE 16-bit type throughout. */
+enum { RU3D_F32 = 0, RU3D_BF16 = 1, RU3D_F16 = 2 };
 
 /* label dtypes accepted by the loss kernels (reference passes int64: loss.py:27) */
 enum { RU3D_LABEL_I64 = 0, RU3D_LABEL_U8 = 1 };
@@ -230,6 +232,13 @@ typedef struct ru3d_adam_tensor {
 int ru3d_adam_multi(const ru3d_adam_tensor* tensors, const int32_t* block_map, int nblocks, int chunk_elems,
                     float lr, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
                     float grad_scale, void* stream);
+
+/* Dynamic loss scaling of the fp16 mode (the reference's apex O1: trainer.py:492-493 amp.scale_loss, 538-542
+ * amp.initialize): every gradient named by the table (same layout as ru3d_adam_multi; only grad / count are read) is
+ * checked for inf / nan - *found_inf is set to 1.0 when one is found; the caller zeroes it beforehand - and multiplied
+ * in place by `scale` (pass 1 / loss_scale; scale == 1 checks without writing). */
+int ru3d_grad_scale_check(const ru3d_adam_tensor* tensors, const int32_t* block_map, int nblocks, int chunk_elems,
+                          float scale, float* found_inf, void* stream);
 
 /* ------------------------------------------------------------------ gradient exchange (RCCL) */
 /* Data-parallel training: one process per GPU, one exchange per step - the mean of the parameter gradients over

@@ -55,8 +55,9 @@ def test_ndhwc_descriptor_logic():
     with pytest.raises(N.Ru3dError):
         N.desc(t)                                               # CPU tensor: refused
     assert N.dtype_code(torch.bfloat16) == N.BF16
+    assert N.dtype_code(torch.float16) == N.F16                 # round 2: the reference's apex-O1 storage type
     with pytest.raises(N.Ru3dError):
-        N.dtype_code(torch.float16)
+        N.dtype_code(torch.float64)
 
 
 def test_state_dict_contract_and_init_parity(golden_dir):
