@@ -440,8 +440,10 @@ int conv_slide_launch(const void* x, const void* w, const float* bias, const voi
 #ifdef RU3D_SLIDE_STAMPS
     a.stamps = g_slide_stamps;
 #endif
-    if (res && stat_slab) hipLaunchKernelGGL((conv3_s1_slide32_kernel<true, true>), dim3(p.grid, p.ny), dim3(256), 0, st, a);
-    else if (res) hipLaunchKernelGGL((conv3_s1_slide32_kernel<true, false>), dim3(p.grid, p.ny), dim3(256), 0, st, a);
+    // residual + statistics together is not a combination any entry point produces (ru3d_conv3d_fwd_in has no
+    // residual), and its instantiation would not fit the register file
+    if (res && stat_slab) return ru3d_fail(-1, "conv_slide: residual and fused statistics cannot be combined");
+    if (res) hipLaunchKernelGGL((conv3_s1_slide32_kernel<true, false>), dim3(p.grid, p.ny), dim3(256), 0, st, a);
     else if (stat_slab) hipLaunchKernelGGL((conv3_s1_slide32_kernel<false, true>), dim3(p.grid, p.ny), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv3_s1_slide32_kernel<false, false>), dim3(p.grid, p.ny), dim3(256), 0, st, a);
     return ru3d_check_launch("conv3_s1_slide32");

@@ -207,10 +207,8 @@ int wgrad_s2_launch(const void* x, const void* dy, float* dw, void* ws, const Wg
     a.tiles_d = g.Do / TDO; a.tiles_h = g.Ho / THO; a.tiles_w = g.Wo / TWO;
     a.ntiles = g.N * a.tiles_d * a.tiles_h * a.tiles_w;
     a.G = s2_groups(g, a.ntiles);
-    const int nco = s2_nco(g);
-    const dim3 grid(a.G, (g.Cin / 32) * (g.Cout / (32 * nco)));
-    if (nco == 2) hipLaunchKernelGGL(wgrad3_s2_tile_kernel<2>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wgrad3_s2_tile_kernel<1>, grid, dim3(256), 0, st, a);
+    const dim3 grid(a.G, (g.Cin / 32) * (g.Cout / 32));
+    hipLaunchKernelGGL(wgrad3_s2_tile_kernel<1>, grid, dim3(256), 0, st, a);   // NCO = 2 does not fit the register file
     int rc = ru3d_check_launch("wgrad3_s2_tile");
     if (rc) return rc;
     return wgrad_reduce_launch((const float*)ws, dw, a.G, 27, g.Cin, g.Cout, g.s_o, g.s_i, st);

@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""ISA check of the hand-scheduled kernels (run on the build box; hipcc cross-compiles, no GPU needed):
+
+    python tools/isa_check.py [--out profiles/rNN_isa_check.txt]
+
+Compiles every kernel source to gfx950 assembly (both storage-type builds), prints a per-kernel table of
+VGPR / AGPR / spill / scratch figures from the code-object metadata, and FAILS (exit 1) when
+  * a kernel that issues inline-asm MFMAs (the D-sliding conv / weight-gradient kernels) has a `scratch_` instruction
+    between its first and last `v_mfma` - the compiler's hazard recogniser cannot see those MFMAs' operands, so a
+    spill restore next to them is the hazard the hand-placed `s_nop`s do not cover (conv_slide.hip step()), or
+  * any kernel on the hot path spills more VGPRs than the committed allowance below (a compiler bump that pushes a
+    512-register kernel over the edge shows up here, not as a silent slowdown).
+"""
+import argparse
+import concurrent.futures as cf
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "3d-unet-renal-anatomy-extraction_amd", "csrc")
+SRCS = ["conv_slide.hip", "wgrad_slide.hip", "wgrad_s2.hip", "conv_mfma.hip", "small_convs.hip", "conv_generic.hip",
+        "norm.hip", "loss.hip", "predict.hip", "comm.hip"]
+TWICE = {"conv_slide.hip", "wgrad_slide.hip", "wgrad_s2.hip", "conv_mfma.hip", "small_convs.hip", "conv_generic.hip",
+         "norm.hip"}
+# spilled VGPRs tolerated per kernel-name pattern (everything else: 0)
+ALLOW = [(r"conv3_s1_slide32_kernel", 64), (r"conv3_s1_pc_kernel", 16), (r"wgrad3_s1_slide_kernel", 16)]
+NO_SCRATCH_IN_MFMA_SPAN = [r"conv3_s1_slide32_kernel", r"wgrad3_s1_slide_kernel"]
+
+
+def compile_asm(src, f16, tmp):
+    out = os.path.join(tmp, src.replace(".hip", "_f16.s" if f16 else ".s"))
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+           "-Wno-unused-function", "-Wno-pass-failed", os.path.join(CSRC, src), "-o", out]
+    if f16:
+        cmd.insert(1, "-DRU3D_STORAGE_F16")
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return out
+
+
+def demangle(names):
+    try:
+        p = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True,
+                           text=True, check=True)
+        return dict(zip(names, p.stdout.splitlines()))
+    except Exception:
+        return {n: n for n in names}
+
+
+def parse(path):
+    text = open(path).read()
+    kernels = {}
+    # bodies: from "<name>:" to the matching ".Lfunc_end"
+    for m in re.finditer(r"^(\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", text, re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        if ".amdhsa_kernel " + name not in text:
+            continue
+        lines = body.splitlines()
+        mf = [i for i, l in enumerate(lines) if "v_mfma" in l]
+        inside = 0
+        if mf:
+            inside = sum(1 for l in lines[mf[0]:mf[-1] + 1] if re.search(r"\bscratch_(load|store)", l))
+        kernels[name] = {"mfma": len(mf), "scratch_in_mfma_span": inside,
+                         "scratch_total": sum(1 for l in lines if re.search(r"\bscratch_(load|store)", l))}
+    for m in re.finditer(r"- \.agpr_count:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?"
+                         r"\.sgpr_count:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", text, re.S):
+        agpr, name, scratch, sgpr, vgpr, spill = m.groups()
+        if name in kernels:
+            kernels[name].update(agpr=int(agpr), scratch_bytes=int(scratch), sgpr=int(sgpr), vgpr=int(vgpr),
+                                 spill=int(spill))
+    return kernels
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    jobs = [(s, False) for s in SRCS] + [(s, True) for s in SRCS if s in TWICE]
+    rows, failures = [], []
+    with tempfile.TemporaryDirectory() as tmp:
+        with cf.ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+            paths = list(ex.map(lambda j: compile_asm(j[0], j[1], tmp), jobs))
+        for (src, f16), path in zip(jobs, paths):
+            ks = parse(path)
+            names = demangle(list(ks))
+            for raw, k in sorted(ks.items(), key=lambda kv: names[kv[0]]):
+                nice = names[raw]
+                nice = re.sub(r"\(anonymous namespace\)::|ru3d_bf16::|ru3d_f16::|void ", "", nice)
+                nice = re.sub(r"\(.*$", "", nice)
+                allow = max([a for pat, a in ALLOW if re.search(pat, nice)] or [0])
+                rows.append((src + (" [f16]" if f16 else ""), nice, k.get("vgpr", -1), k.get("agpr", -1),
+                             k.get("sgpr", -1), k.get("spill", -1), k.get("scratch_bytes", -1), k["mfma"],
+                             k["scratch_in_mfma_span"]))
+                if k.get("spill", 0) > allow:
+                    failures.append("%s: %s spills %d VGPRs (allowance %d)" % (src, nice, k["spill"], allow))
+                if any(re.search(p, nice) for p in NO_SCRATCH_IN_MFMA_SPAN) and k["scratch_in_mfma_span"]:
+                    failures.append("%s: %s has %d scratch instruction(s) between its first and last v_mfma"
+                                    % (src, nice, k["scratch_in_mfma_span"]))
+    lines = ["%-24s %-62s %5s %5s %5s %6s %8s %6s %s" % ("source", "kernel", "vgpr", "agpr", "sgpr", "spill", "scratchB",
+                                                          "mfma", "scratch-in-mfma-span")]
+    for r in rows:
+        lines.append("%-24s %-62s %5d %5d %5d %6d %8d %6d %d" % (r[0], r[1][:62], *r[2:]))
+    lines.append("")
+    lines.append("FAILURES: %d" % len(failures))
+    lines += failures
+    text = "\n".join(lines)
+    print(text)
+    if args.out:
+        with open(args.out, "w") as f:
+            f.write(text + "\n")
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()
