@@ -33,6 +33,15 @@ class PackItem(ctypes.Structure):
                 ("cout_seg", ctypes.c_int32), ("cin_seg", ctypes.c_int32)]
 
 
+class PatchParams(ctypes.Structure):
+    """struct ru3d_patch_params"""
+    _fields_ = [("lo", ctypes.c_int32 * 3), ("before", ctypes.c_int32 * 3), ("patch", ctypes.c_int32 * 3),
+                ("flip", ctypes.c_int32 * 3), ("image_cval", ctypes.c_float), ("label_cval", ctypes.c_int32),
+                ("do_contrast", ctypes.c_int32), ("do_brightness", ctypes.c_int32), ("do_gamma", ctypes.c_int32),
+                ("contrast", ctypes.c_float), ("brightness", ctypes.c_float), ("gamma", ctypes.c_float),
+                ("gamma_eps", ctypes.c_float)]
+
+
 PACK_MAX = 12
 _P = ctypes.POINTER(Tensor)
 _vp, _i, _i64, _f, _sz, _u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t,
@@ -78,6 +87,11 @@ SIGNATURES = {
     "ru3d_predict_merge": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ru3d_adam_multi": (_i, [_vp, _vp, _i, _i, _f, _f, _f, _f, _f, _f, _f, _vp]),
     "ru3d_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp]),
+    "ru3d_augment_workspace_bytes": (_sz, [_i, _i, _i]),
+    "ru3d_augment_label_presence": (_i, [_vp, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int32),
+                                        ctypes.POINTER(ctypes.c_int32), _i, _vp, _vp]),
+    "ru3d_augment_patch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(PatchParams), _vp, _vp, _vp, _vp, _sz,
+                               _vp]),
     "ru3d_grad_scale_check": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp]),
     "ru3d_comm_unique_id": (_i, [_vp]),
     "ru3d_comm_init": (_i, [ctypes.POINTER(_vp), _vp, _i, _i, _i]),

@@ -212,6 +212,34 @@ int ru3d_predict_accumulate(const ru3d_tensor* logits, int dtype, int sample, fl
 int ru3d_predict_merge(const float* acc, const float* cnt, int X, int Y, int Z, int num_classes, int cx, int cy,
                        int cz, int sx, int sy, int sz, int one_hot, void* out, void* stream);
 
+/* ------------------------------------------------------------------ patch sampling + augmentation */
+/* The reference's training transform chain on the device: RandomRescaleCrop -> RandomMirror ->
+ * RandomContrast -> RandomBrightness -> RandomGamma -> ToTensor (transform.py:573-652, 279-301, 176-259, 156-163;
+ * nb_train_iia.py:30-39).  The HOST makes the random draws (in the reference's order) and passes them here; the
+ * kernels are deterministic.  image: fp32 volume [X][Y][Z][C] (the reference's channels-last case layout), label:
+ * [X][Y][Z] uint8 or int64.  out_image: fp32 [C][px][py][pz] (ToTensor layout = one NCDHW sample), out_label: int64
+ * [px][py][pz].  Resampling restates scipy.ndimage.zoom(order=1): corner-aligned linear interpolation in float64. */
+typedef struct ru3d_patch_params {
+    int32_t lo[3];      /* crop box lower corner in the volume, per axis (may lie outside: constant padding)      */
+    int32_t before[3];  /* crop box size = round(patch / scale), transform.py:617                                  */
+    int32_t patch[3];   /* output patch size                                                                       */
+    int32_t flip[3];    /* RandomMirror: reverse this output axis                                                   */
+    float image_cval;   /* image_pad_cval                                                                           */
+    int32_t label_cval; /* label_pad_cval                                                                           */
+    int32_t do_contrast, do_brightness, do_gamma;
+    float contrast, brightness, gamma; /* the drawn factors                                                         */
+    float gamma_eps;    /* adjust_gamma's epsilon (1e-7), transform.py:188                                          */
+} ru3d_patch_params;
+size_t ru3d_augment_workspace_bytes(int px, int py, int pz);
+/* mask (1 device uint32): bit min(v, 31) set for every label value v inside the crop box (pad value included). */
+int ru3d_augment_label_presence(const void* label, int label_dtype, int X, int Y, int Z, const int32_t* lo,
+                                const int32_t* before, int label_cval, uint32_t* mask, void* stream);
+/* label / out_label may both be NULL (image only).  presence_mask: device uint32 from the call above (the label rule
+ * of transform.py:47-48 needs the number of classes in the crop); NULL = treat as >= 3 classes. */
+int ru3d_augment_patch(const float* image, const void* label, int label_dtype, int X, int Y, int Z, int C,
+                       const ru3d_patch_params* p, const uint32_t* presence_mask, float* out_image, int64_t* out_label,
+                       void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------ optimizer --------------- */
 /* torch.optim.Adam step (nb_train_iia.py:18 defaults), fused over one flat fp32 parameter run.
  * grad may be bf16/f32 (grad_dtype); bias corrections are passed in by the host. */

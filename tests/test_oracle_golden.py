@@ -250,3 +250,32 @@ def test_g6_predict_per_patch_matches_reference(golden_dir, tag):
     if tag in "abd":
         assert np.isnan(gp).any()          # the quirk is really in the fixture: part of the far border is never visited
         assert (gm[np.isnan(gp).any(axis=-1)] == 0).all()
+
+
+# --------------------------------------------------------------------------- G7: patch sampling / augmentation
+G7_CASES = {
+    "iia_like": dict(scale=0.1, crop_mode="random"),
+    "iia_like_b": dict(scale=0.1, crop_mode="random"),
+    "binary_label": dict(scale=0.2, crop_mode="random"),
+    "pads": dict(scale=0.1, crop_mode="random"),
+    "center_two_ch": dict(scale=[0.8, 1.3], crop_mode="center"),
+    "margin_enforce": dict(scale=0.1, crop_mode="random", crop_margin=4, enforce_label_indices=[2]),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(G7_CASES))
+def test_g7_augment_oracle_matches_reference_pipeline(golden_dir, tag):
+    """oracle/augment_oracle.pipeline under the fixture's numpy seed == the reference's transform pipeline
+    (nb_train_iia.py:30-39) run by make_golden_augment.py: the same random draws in the same order, labels
+    identical, resampled image within 2e-6 (float64 interpolation rounded to float32 on both sides), intensity chain
+    within 1e-5 (float32 mean / power)."""
+    from oracle import augment_oracle as A
+    z = np.load(os.path.join(golden_dir, "g7_augment.npz"))
+    np.random.seed(int(z[tag + "/seed"]))
+    img, lab, after_crop, after_mirror = A.pipeline(z[tag + "/image_in"], z[tag + "/label_in"],
+                                                    tuple(int(v) for v in z[tag + "/patch"]), **G7_CASES[tag])
+    assert np.array_equal(lab, z[tag + "/label_out"])
+    assert np.abs(after_crop - z[tag + "/after_crop"]).max() <= 2e-6
+    assert np.abs(after_mirror - z[tag + "/after_mirror"]).max() <= 2e-6
+    assert img.shape == z[tag + "/image_out"].shape and img.dtype == np.float32
+    assert np.abs(img - z[tag + "/image_out"]).max() <= 1e-5
