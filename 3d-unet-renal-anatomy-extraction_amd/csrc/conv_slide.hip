@@ -35,7 +35,7 @@ constexpr int PLANE = PROWS * PITCH;  // bf16 elements per plane
 constexpr int RING = 4;
 constexpr int WAVE_ROWS = PROWS / 4;  // 85 rows of a plane are staged by each wave
 constexpr int EST_PITCH = 36;         // floats per epilogue-patch row (32 channels + 4 pad = 144 bytes)
-constexpr int XG = 2;                 // fragment ring depth in groups (prefetch XG - 1 groups ahead)
+constexpr int XG = 1;                 // activation-fragment register sets (rows are refilled one by one, see frag_row)
 constexpr int NG = 18;                // (kd, kw, k-step) groups per step, 6 MFMAs each
 constexpr int NSTG = 6;               // 16-byte pieces staged per thread and plane (85 rows x 4 pieces / 64 lanes)
 static_assert(PROWS % 4 == 0, "plane rows split evenly over 4 waves");
@@ -205,6 +205,23 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
             }
         };
 
+        // one 16-byte piece at a time (steady state): the plane staging is spread over the MFMA groups behind the
+        // step's barrier - as one block it kept the matrix pipe idle for ~1000 of a step's ~6500 cycles
+        auto load_piece = [&](int pr, auto ic, bf16x8 (&stg)[NSTG]) {
+            constexpr int i = decltype(ic)::value;
+            int d = d0 - 1 + pr;
+            d = d < 0 ? 0 : (d >= a.D ? a.D - 1 : d);
+            const bf16* src = a.x + ((int64_t)n * a.D + d) * plane_stride;
+            stg[i] = *reinterpret_cast<const bf16x8*>(src + soff[i]);
+        };
+        auto store_piece = [&](int pr, int slot, auto ic, const bf16x8 (&stg)[NSTG]) {
+            constexpr int i = decltype(ic)::value;
+            const int d = d0 - 1 + pr;
+            const bool dok = d >= 0 && d < a.D;
+            const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (szh[i] >= 0) *reinterpret_cast<bf16x8*>(lds + slot * PLANE + sdst[i]) = (dok && ok[i]) ? stg[i] : z8;
+        };
+
         __syncthreads();   // the previous unit has left the ring
         bf16x8 stg[NSTG];   // the plane in flight: loaded behind one step's barrier, stored behind the next one's
         load_plane(0, stg);
@@ -223,13 +240,18 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
             for (int i = 0; i < 8; i++) st1[i] = st2[i] = 0.f;
         }
 
-        // ---- fragment ring, continuous across the steps of a unit: group `g` = (kd, kw, ks) of the step with phase PHN
-        auto frag_fetch = [&](auto phn, auto gc, int ring) {
-            constexpr int PHN = decltype(phn)::value, g = decltype(gc)::value;
+        // ---- activation fragments, continuous across the steps of a unit: group `g` = (kd, kw, ks) of the step with
+        // phase PHN needs input rows 2*wave .. 2*wave + 3.  ONE register set: row r of the next group is fetched right
+        // behind the last MFMA of the current group that reads row r (rows 0..3 fall free after MFMAs 0, 2, 4, 5), so
+        // every LDS read has four to five MFMAs (128-160 cycles) to land - issued in a block behind the sixth MFMA they
+        // left the matrix pipe idle for an LDS latency in every group.
+        auto frag_row = [&](auto phn, auto gc, auto rc) {
+            constexpr int PHN = decltype(phn)::value, g = decltype(gc)::value, r = decltype(rc)::value;
             constexpr int kd = g / 6, kw = (g % 6) >> 1, ks = g & 1;
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                xq[ring][r] = *reinterpret_cast<const bf16x8*>(bl + ((PHN + kd) & 3) * PLANE + (r * WW + kw) * PITCH + ks * 16);
+            xq[0][r] = *reinterpret_cast<const bf16x8*>(bl + ((PHN + kd) & 3) * PLANE + (r * WW + kw) * PITCH + ks * 16);
+        };
+        auto frag_fetch = [&](auto phn, auto gc) {
+            static_for<0, 4>([&](auto rc) { frag_row(phn, gc, rc); });
         };
         // ---- epilogue pieces of a finished step (accumulators `ac`, output plane d0 + sp): accumulator layout
         // (lane = voxel, 4 couts per 8 bytes) -> wave-private LDS patch -> 16-byte stores that cover whole
@@ -294,29 +316,43 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
             static_for<0, NG>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
                 constexpr int kd = g / 6, kw = (g % 6) >> 1, ks = g & 1;
+                if constexpr (g == 11) {
+                    // the kd = 2 groups (12..17) read the plane that was stored behind the PREVIOUS step's barrier, and
+                    // their fragments are fetched during group 11; every wave is past the kd = 0 groups of this step,
+                    // so the slot of plane s-1 is free
+                    SLIDE_STAMP(PH, 19, s)
+                    __syncthreads();
+                    SLIDE_STAMP(PH, 20, s)
+                    SLIDE_STAMP(PH, 21, s)
+                }
                 // output row m, tap row kh reads input row m + kh; the two accumulators alternate
                 static_for<0, 6>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
                     constexpr int m = j & 1, kh = j >> 1;
                     constexpr int f = ((kd * 3 + kh) * 3 + kw) * 2 + ks;
-                    mfma_w<(f < WA_FRAGS), (g == 0 && kh == 0)>(acc[PAR][m], wreg[f], xq[g % XG][m + kh]);
+                    mfma_w<(f < WA_FRAGS), (g == 0 && kh == 0)>(acc[PAR][m], wreg[f], xq[0][m + kh]);
+                    // plane staging, one piece per group behind the barrier of group 11: piece i of plane s+3 goes to LDS
+                    // in group 11 + i (its slot, that of plane s-1, is free behind the barrier; first read in the next
+                    // step's kd = 2 groups, behind that step's barrier), and piece i of plane s+4 is loaded into the
+                    // freed registers one group later.  Unconditional (planes beyond the unit are clamped / land in a
+                    // slot nobody reads again): a conditional store hides from the compiler that the loads were waited for
+                    if constexpr (j == 1 && g >= 11 && g < 11 + NSTG)
+                        store_piece(s + 3, (PH + 3) & 3, std::integral_constant<int, g - 11>{}, stg);
+                    if constexpr (j == 3 && g >= 12 && g < 12 + NSTG)
+                        load_piece(s + 4, std::integral_constant<int, g - 12>{}, stg);
+                    constexpr int row = j == 0 ? 0 : (j == 2 ? 1 : (j == 4 ? 2 : (j == 5 ? 3 : -1)));
+                    if constexpr (row >= 0) {
+                        if constexpr (g + 1 < NG) {
+                            frag_row(std::integral_constant<int, PH>{}, std::integral_constant<int, g + 1>{},
+                                     std::integral_constant<int, row>{});
+                        } else {
+                            if (!last)
+                                frag_row(std::integral_constant<int, (PH + 1) & 3>{}, std::integral_constant<int, 0>{},
+                                         std::integral_constant<int, row>{});
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 });
-                if constexpr (g == 12 - (XG - 1)) {
-                    // the kd = 2 groups (12..17) read the plane that was stored behind the PREVIOUS step's barrier;
-                    // every wave is past the kd = 0 groups of this step, so the slot of plane s-1 is free
-                    SLIDE_STAMP(PH, 19, s)
-                    __syncthreads();
-                    SLIDE_STAMP(PH, 20, s)
-                    if (s + 3 <= a.DL + 1) store_plane(s + 3, (PH + 3) & 3, stg);
-                    SLIDE_STAMP(PH, 21, s)
-                }
-                if constexpr (g + XG - 1 < NG) {
-                    frag_fetch(std::integral_constant<int, PH>{}, std::integral_constant<int, g + XG - 1>{}, (g + XG - 1) % XG);
-                } else {
-                    if (!last)
-                        frag_fetch(std::integral_constant<int, (PH + 1) & 3>{},
-                                   std::integral_constant<int, g + XG - 1 - NG>{}, (g + XG - 1) % XG);
-                }
                 // epilogue of the previous plane, spread over the groups: 8 patch writes, then 4 rows (load | finish)
                 if constexpr (g <= 7) {
                     if (has_prev) epi_write(acc[PAR ^ 1], g >> 2, g & 3);
@@ -328,10 +364,6 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
                     if (has_prev) epi_row_finish(s - 1, (g - 8) >> 1, rv, rq[(g - 8) >> 1]);
                 }
                 if constexpr (g == 16) {
-                    // behind the last store of the step: vmcnt retires in order, and the next store's reuse of its
-                    // data registers waits for the previous store - it must not find these loads in front of it.
-                    // Stored to LDS behind the next step's barrier, two thirds of a step from now.
-                    if (s + 4 <= a.DL + 1) load_plane(s + 4, stg);
                     SLIDE_STAMP(PH, 22, s)
                 }
                 SLIDE_STAMP(PH, g + 1, s)
@@ -339,8 +371,8 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(SlideArgs a) {
             });
         };
 
-        // first fragments of step 0
-        static_for<0, XG - 1>([&](auto gc) { frag_fetch(std::integral_constant<int, 0>{}, gc, decltype(gc)::value); });
+        // fragments of the first group of step 0
+        frag_fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         for (int s4 = 0; s4 < a.DL; s4 += 4) {
             step(std::integral_constant<int, 0>{}, s4);
             step(std::integral_constant<int, 1>{}, s4 + 1);

@@ -2,7 +2,7 @@
 sliding 32->32 conv kernel at every (kd, kw, k-step) group boundary of four steady-state steps (one per ring phase)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["RU3D_LIB"] = os.path.join(ROOT, "3d-unet-renal-anatomy-extraction_amd", "libru3d_stamps.so")
+os.environ["RU3D_LIB"] = os.environ.get("RU3D_STAMPS_LIB") or os.path.join(ROOT, "3d-unet-renal-anatomy-extraction_amd", "libru3d_stamps.so")
 import torch
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "3d-unet-renal-anatomy-extraction_amd"))
 import _native as N, _ops as ops
