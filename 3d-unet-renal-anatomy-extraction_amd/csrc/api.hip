@@ -136,6 +136,46 @@ extern "C" int ru3d_pack_weights(const ru3d_pack_item* items, int count, int dty
         p.cout_pad = generic_cout_pad(kout_p);
         p.total = p.mfma ? (int64_t)taps * kin_p * kout_p : (int64_t)taps * kin_p * p.cout_pad;
     }
+    // MFMA forms whose packed extents are multiples of 32 go through the fused kernel: one read of the source serves the
+    // forward and the input-gradient role of the same weight (the usual request: a ResBlock packs both for each conv)
+    PackPairBatch pairs;
+    pairs.count = 0;
+    if (dtype == RU3D_BF16) {
+        for (int i = 0; i < count; i++) {
+            PackOne& p = b.item[i];
+            const ru3d_pack_item& it = items[i];
+            if (p.mfma != 1 || (p.cin % 32) || (p.cout % 32) || p.taps > 27) continue;
+            // source [a][b][tap]: Conv3d a = cout, ConvTranspose3d a = cin; a-major form = the role whose kout is a
+            const bool is_t = it.role == RU3D_ROLE_CONVT_FWD || it.role == RU3D_ROLE_CONVT_DGRAD;
+            const bool a_major = it.role == RU3D_ROLE_CONV_FWD || it.role == RU3D_ROLE_CONVT_DGRAD;
+            const int a_seg = is_t ? it.cin_seg : it.cout_seg, b_seg = is_t ? it.cout_seg : it.cin_seg;
+            const int a_realdim = is_t ? it.cin : it.cout, b_realdim = is_t ? it.cout : it.cin;
+            int slot = -1;
+            for (int j = 0; j < pairs.count; j++)
+                if (pairs.item[j].src == it.src && pairs.item[j].taps == p.taps &&
+                    pairs.item[j].adim == padded_dim(a_realdim, a_seg) && pairs.item[j].bdim == padded_dim(b_realdim, b_seg) &&
+                    pairs.item[j].a_real == a_seg && pairs.item[j].b_real == b_seg &&
+                    (a_major ? !pairs.item[j].dst_a : !pairs.item[j].dst_b))
+                    slot = j;
+            if (slot < 0) {
+                slot = pairs.count++;
+                PackPair& q = pairs.item[slot];
+                q.src = it.src; q.dst_a = nullptr; q.dst_b = nullptr;
+                q.adim = padded_dim(a_realdim, a_seg); q.bdim = padded_dim(b_realdim, b_seg); q.taps = p.taps;
+                q.a_real = a_seg; q.a_pad = a_seg ? pad32(a_seg) : 0;
+                q.b_real = b_seg; q.b_pad = b_seg ? pad32(b_seg) : 0;
+                q.s_a = (int64_t)b_realdim * p.taps;
+            }
+            (a_major ? pairs.item[slot].dst_a : pairs.item[slot].dst_b) = p.dst;
+            p.mfma = 3;   // handled by the fused kernel: pack_batch_kernel skips it
+        }
+    }
+    bool rest = false;
+    for (int i = 0; i < count; i++) rest = rest || b.item[i].mfma != 3;
+    if (pairs.count) {
+        int rc = pack_pair_launch(pairs, as_stream(stream));
+        if (rc || !rest) return rc;
+    }
     return pack_batch_launch(b, dtype, as_stream(stream));
 }
 

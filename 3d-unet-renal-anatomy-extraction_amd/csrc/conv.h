@@ -38,6 +38,24 @@ struct PackBatch {
     PackOne item[RU3D_PACK_MAX];
 };
 int pack_batch_launch(const PackBatch& b, int dtype, hipStream_t st);
+
+// Fused packing of the two MFMA roles of one weight (forward + input gradient) from ONE read of the fp32 source:
+// the source is [a][b][tap] (Conv3d: a = cout, b = cin; ConvTranspose3d: a = cin, b = cout); dst_a is the packed form
+// whose output-channel dimension is a (Conv forward / ConvTranspose input gradient), dst_b the one whose output-channel
+// dimension is b.  Either may be NULL.  adim / bdim are the PACKED (padded) extents, multiples of 32.
+struct PackPair {
+    const float* src;
+    void* dst_a;
+    void* dst_b;
+    int adim, bdim, taps;
+    int a_real, a_pad, b_real, b_pad;   // channel padding per segment (pad == 0: none), see pack_src_index
+    int64_t s_a;                        // source stride of a (= real bdim * taps); b has stride taps, tap stride 1
+};
+struct PackPairBatch {
+    int count;
+    PackPair item[RU3D_PACK_MAX];
+};
+int pack_pair_launch(const PackPairBatch& b, hipStream_t st);
 int unpad_weight_launch(const float* src, float* dst, int cout, int cin, int taps, int co_real, int co_pad, int ci_real,
                         int ci_pad, int cin_p, hipStream_t st);
 

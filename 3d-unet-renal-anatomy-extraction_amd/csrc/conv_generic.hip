@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(PackBatch b) {
     const PackOne& p = b.item[blockIdx.y];
     T* dst = (T*)p.dst;
     const int taps = p.taps;
+    if (p.mfma == 3) return;   // packed by pack_pair_kernel
     if (p.mfma == 2) {   // bias vector: fp32, zero-padded per segment
         float* out = (float*)p.dst;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < p.cout; i += gridDim.x * 256) {
@@ -266,6 +267,70 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(PackBatch b) {
         }
         dst[i] = from_f32<T>(v);
     }
+}
+
+// ---- both MFMA roles of a weight from one read of the source (see PackPair in conv.h).  A workgroup owns one
+// (32 a) x (32 b) x taps block: it reads 32 contiguous runs of 32 * taps floats, keeps the block in LDS as 16-bit
+// [tap][a][b] (pitch 40: the 16-byte reads of the a-major form and the 2-byte strided reads of the b-major form both
+// spread over the banks) and writes, per tap, two 1-KiB fragments of each packed form.  The per-role kernel above read
+// the source once per role and ran at 1.5 TB/s; the weights are 0.4 GB of fp32 per step at BASELINE config 2.
+#define PP_PITCH 40
+__global__ __launch_bounds__(256) void pack_pair_kernel(PackPairBatch pb) {
+    __shared__ __attribute__((aligned(16))) bf16 tile[27 * 32 * PP_PITCH];
+    const PackPair& p = pb.item[blockIdx.y];
+    const int taps = p.taps;
+    const int TA = p.adim / 32, TB = p.bdim / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int unit = blockIdx.x; unit < TA * TB; unit += gridDim.x) {
+        const int ta = unit / TB, tb = unit % TB;
+        // real source channels covered by this block (a 32-channel block never straddles a padded segment)
+        const int a_s = pack_src_index(ta * 32, p.a_real, p.a_pad), b_s = pack_src_index(tb * 32, p.b_real, p.b_pad);
+        int a_n = 32, b_n = 32;
+        if (p.a_pad) a_n = a_s < 0 ? 0 : min(32, p.a_real - (ta * 32) % p.a_pad);
+        if (p.b_pad) b_n = b_s < 0 ? 0 : min(32, p.b_real - (tb * 32) % p.b_pad);
+        const float* base = p.src + (int64_t)(a_s < 0 ? 0 : a_s) * p.s_a + (int64_t)(b_s < 0 ? 0 : b_s) * taps;
+        const int run = 32 * taps, run_n = b_n * taps;
+        __syncthreads();
+        for (int e = threadIdx.x; e < 32 * run; e += 256) {
+            const int a = e / run, j = e - a * run;
+            const int b = j / taps, tap = j - b * taps;
+            const float v = (a < a_n && j < run_n) ? base[(int64_t)a * p.s_a + j] : 0.f;
+            tile[(tap * 32 + a) * PP_PITCH + b] = (bf16)v;
+        }
+        __syncthreads();
+        // a-major form: fragment (tap, ks = 2 tb + kc, nt = ta): lane -> a = lane & 31, 8 consecutive b from 16 kc + 8 (lane >> 5)
+        if (p.dst_a) {
+            const int KS = p.bdim / 16, NTT = TA;
+            for (int f = wave; f < taps * 2; f += 4) {
+                const int tap = f >> 1, kc = f & 1;
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(&tile[(tap * 32 + (lane & 31)) * PP_PITCH + 16 * kc + 8 * (lane >> 5)]);
+                *reinterpret_cast<bf16x8*>((bf16*)p.dst_a + ((((int64_t)tap * KS + 2 * tb + kc) * NTT + ta) * 64 + lane) * 8) = v;
+            }
+        }
+        // b-major form: fragment (tap, ks = 2 ta + kc, nt = tb): lane -> b = lane & 31, 8 consecutive a
+        if (p.dst_b) {
+            const int KS = p.adim / 16, NTT = TB;
+            for (int f = wave; f < taps * 2; f += 4) {
+                const int tap = f >> 1, kc = f & 1;
+                const int a0 = 16 * kc + 8 * (lane >> 5);
+                bf16x8 v;
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = tile[(tap * 32 + a0 + j) * PP_PITCH + (lane & 31)];
+                *reinterpret_cast<bf16x8*>((bf16*)p.dst_b + ((((int64_t)tap * KS + 2 * ta + kc) * NTT + tb) * 64 + lane) * 8) = v;
+            }
+        }
+    }
+}
+
+int pack_pair_launch(const PackPairBatch& b, hipStream_t st) {
+    int64_t mx = 1;
+    for (int i = 0; i < b.count; i++) {
+        const int64_t units = (int64_t)(b.item[i].adim / 32) * (b.item[i].bdim / 32);
+        mx = units > mx ? units : mx;
+    }
+    if (mx > 1024) mx = 1024;
+    hipLaunchKernelGGL(pack_pair_kernel, dim3((unsigned)mx, b.count), dim3(256), 0, st, b);
+    return ru3d_check_launch("pack_pair");
 }
 
 // dst[co][ci][tap] = src[co_p][ci_p][tap]: drops the zero rows / columns of a weight gradient computed on padded channels

@@ -195,3 +195,23 @@ def test_checkpointing_gradients_bit_equal_and_memory_drops(dtype, feat):
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
     assert held1 < 0.62 * held0, (held0, held1)
+
+
+@pytest.mark.parametrize("cout,cin,k,stride,conv_t", [(32, 32, 3, 1, False), (64, 32, 3, 2, False), (128, 64, 3, 1, False),
+                                                      (32, 64, 1, 1, False), (64, 128, 3, 2, True), (96, 32, 3, 1, False)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fused_two_role_pack_equals_single_role_packs(cout, cin, k, stride, conv_t, dtype):
+    """ru3d_pack_weights packs the forward and the input-gradient form of a weight from one read of the source
+    (pack_pair_kernel); each must equal what the one-weight entry point ru3d_pack_weight (element-wise gather kernel)
+    produces for that role - also when only one of the two roles is requested."""
+    g = torch.Generator().manual_seed(cout + 7 * cin + k)
+    shape = (cin, cout, k, k, k) if conv_t else (cout, cin, k, k, k)
+    w = torch.randn(shape, generator=g).to(DEV)
+    roles = (N.ROLE_CONVT_FWD, N.ROLE_CONVT_DGRAD) if conv_t else (N.ROLE_CONV_FWD, N.ROLE_CONV_DGRAD)
+    both = ops.pack_weights([(w, roles[0], stride), (w, roles[1], stride)], dtype)
+    for role, got in zip(roles, both):
+        ref = ops.pack_weight(w, role, dtype, stride)
+        single = ops.pack_weights([(w, role, stride)], dtype)[0]
+        torch.cuda.synchronize()
+        n = ref.numel()
+        assert torch.equal(got[:n], ref) and torch.equal(single[:n], ref), role
