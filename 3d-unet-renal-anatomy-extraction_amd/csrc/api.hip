@@ -144,7 +144,7 @@ extern "C" int ru3d_pack_weights(const ru3d_pack_item* items, int count, int dty
         for (int i = 0; i < count; i++) {
             PackOne& p = b.item[i];
             const ru3d_pack_item& it = items[i];
-            if (p.mfma != 1 || (p.cin % 32) || (p.cout % 32) || p.taps > 27) continue;
+            if (p.mfma != 1 || (p.cin % 32) || (p.cout % 32) || (p.taps != 27 && p.taps != 1)) continue;
             // source [a][b][tap]: Conv3d a = cout, ConvTranspose3d a = cin; a-major form = the role whose kout is a
             const bool is_t = it.role == RU3D_ROLE_CONVT_FWD || it.role == RU3D_ROLE_CONVT_DGRAD;
             const bool a_major = it.role == RU3D_ROLE_CONV_FWD || it.role == RU3D_ROLE_CONVT_DGRAD;

@@ -275,10 +275,13 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(PackBatch b) {
 // spread over the banks) and writes, per tap, two 1-KiB fragments of each packed form.  The per-role kernel above read
 // the source once per role and ran at 1.5 TB/s; the weights are 0.4 GB of fp32 per step at BASELINE config 2.
 #define PP_PITCH 40
+#define PP_PLANE (32 * PP_PITCH + 8)   // per-tap plane: 644 dwords, so the tap-fastest fill spreads over the banks
+template <int TAPS>   // compile-time (27 or 1): the fill loop's index arithmetic divides by it
 __global__ __launch_bounds__(256) void pack_pair_kernel(PackPairBatch pb) {
-    __shared__ __attribute__((aligned(16))) bf16 tile[27 * 32 * PP_PITCH];
+    __shared__ __attribute__((aligned(16))) bf16 tile[TAPS * PP_PLANE];
     const PackPair& p = pb.item[blockIdx.y];
-    const int taps = p.taps;
+    if (p.taps != TAPS) return;
+    constexpr int taps = TAPS;
     const int TA = p.adim / 32, TB = p.bdim / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int unit = blockIdx.x; unit < TA * TB; unit += gridDim.x) {
@@ -289,13 +292,56 @@ __global__ __launch_bounds__(256) void pack_pair_kernel(PackPairBatch pb) {
         if (p.a_pad) a_n = a_s < 0 ? 0 : min(32, p.a_real - (ta * 32) % p.a_pad);
         if (p.b_pad) b_n = b_s < 0 ? 0 : min(32, p.b_real - (tb * 32) % p.b_pad);
         const float* base = p.src + (int64_t)(a_s < 0 ? 0 : a_s) * p.s_a + (int64_t)(b_s < 0 ? 0 : b_s) * taps;
-        const int run = 32 * taps, run_n = b_n * taps;
+        constexpr int run = 32 * taps;
+        const int run_n = b_n * taps;
         __syncthreads();
-        for (int e = threadIdx.x; e < 32 * run; e += 256) {
-            const int a = e / run, j = e - a * run;
-            const int b = j / taps, tap = j - b * taps;
-            const float v = (a < a_n && j < run_n) ? base[(int64_t)a * p.s_a + j] : 0.f;
-            tile[(tap * 32 + a) * PP_PITCH + b] = (bf16)v;
+        const bool vec_ok = ((p.s_a | run_n) & 3) == 0 && ((((uintptr_t)base) & 15) == 0);
+        if (vec_ok) {
+            // 16-byte loads, eight in flight per thread (128 B): with 4-byte loads and four in flight a CU had 8 KB on
+            // the wire and the kernel ran at HBM latency, not bandwidth
+            constexpr int run4 = run / 4;
+            for (int e0 = threadIdx.x; e0 < 32 * run4; e0 += 8 * 256) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int e = e0 + u * 256;
+                    const int a = e / run4, j4 = e - a * run4;
+                    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                    v[u] = (e < 32 * run4 && a < a_n && 4 * j4 < run_n)
+                               ? *reinterpret_cast<const f32x4*>(base + (int64_t)a * p.s_a + 4 * j4) : z4;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int e = e0 + u * 256;
+                    if (e < 32 * run4) {
+                        const int a = e / run4, j4 = e - a * run4;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int j = 4 * j4 + q;
+                            const int b = j / taps, tap = j - b * taps;
+                            tile[tap * PP_PLANE + a * PP_PITCH + b] = (bf16)v[u][q];
+                        }
+                    }
+                }
+            }
+        } else {
+            // four loads in flight per thread before the first LDS store
+            for (int e0 = threadIdx.x; e0 < 32 * run; e0 += 4 * 256) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int e = e0 + u * 256;
+                    const int a = e / run, j = e - a * run;
+                    v[u] = (e < 32 * run && a < a_n && j < run_n) ? base[(int64_t)a * p.s_a + j] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int e = e0 + u * 256;
+                    const int a = e / run, j = e - a * run;
+                    const int b = j / taps, tap = j - b * taps;
+                    if (e < 32 * run) tile[tap * PP_PLANE + a * PP_PITCH + b] = (bf16)v[u];
+                }
+            }
         }
         __syncthreads();
         // a-major form: fragment (tap, ks = 2 tb + kc, nt = ta): lane -> a = lane & 31, 8 consecutive b from 16 kc + 8 (lane >> 5)
@@ -303,7 +349,7 @@ __global__ __launch_bounds__(256) void pack_pair_kernel(PackPairBatch pb) {
             const int KS = p.bdim / 16, NTT = TA;
             for (int f = wave; f < taps * 2; f += 4) {
                 const int tap = f >> 1, kc = f & 1;
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(&tile[(tap * 32 + (lane & 31)) * PP_PITCH + 16 * kc + 8 * (lane >> 5)]);
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(&tile[tap * PP_PLANE + (lane & 31) * PP_PITCH + 16 * kc + 8 * (lane >> 5)]);
                 *reinterpret_cast<bf16x8*>((bf16*)p.dst_a + ((((int64_t)tap * KS + 2 * tb + kc) * NTT + ta) * 64 + lane) * 8) = v;
             }
         }
@@ -315,7 +361,7 @@ __global__ __launch_bounds__(256) void pack_pair_kernel(PackPairBatch pb) {
                 const int a0 = 16 * kc + 8 * (lane >> 5);
                 bf16x8 v;
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = tile[(tap * 32 + a0 + j) * PP_PITCH + (lane & 31)];
+                for (int j = 0; j < 8; j++) v[j] = tile[tap * PP_PLANE + (a0 + j) * PP_PITCH + (lane & 31)];
                 *reinterpret_cast<bf16x8*>((bf16*)p.dst_b + ((((int64_t)tap * KS + 2 * ta + kc) * NTT + tb) * 64 + lane) * 8) = v;
             }
         }
@@ -329,7 +375,13 @@ int pack_pair_launch(const PackPairBatch& b, hipStream_t st) {
         mx = units > mx ? units : mx;
     }
     if (mx > 1024) mx = 1024;
-    hipLaunchKernelGGL(pack_pair_kernel, dim3((unsigned)mx, b.count), dim3(256), 0, st, b);
+    bool t27 = false, t1 = false;
+    for (int i = 0; i < b.count; i++) {
+        t27 = t27 || b.item[i].taps == 27;
+        t1 = t1 || b.item[i].taps == 1;
+    }
+    if (t27) hipLaunchKernelGGL(pack_pair_kernel<27>, dim3((unsigned)mx, b.count), dim3(256), 0, st, b);
+    if (t1) hipLaunchKernelGGL(pack_pair_kernel<1>, dim3((unsigned)mx, b.count), dim3(256), 0, st, b);
     return ru3d_check_launch("pack_pair");
 }
 
