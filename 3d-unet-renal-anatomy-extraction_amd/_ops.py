@@ -487,6 +487,28 @@ def _join(device, *outs):
             t.record_stream(cur)
 
 
+# --------------------------------------------------------------------------- skip connection plumbing
+class SkipLink:
+    """One encoder -> decoder skip connection of a native U-Net (reference network.py:553-563: `skips.append(x)`,
+    later `torch.cat((up, skip), dim=1)`).  Two copies disappear through it:
+      * forward: the encoder block that produces the skip writes it straight into the second half of the buffer the
+        decoder will use as its concat input (`buf`, allocated when the skip is produced), so UpFn has no channel copy
+        to make;
+      * backward: the skip tensor feeds the pooling block and the concat, and autograd would add the two gradients with
+        an elementwise kernel; UpFn instead parks the concat's share here (`grad`) and the pooling ResBlock's last input
+        gradient kernel adds it as its residual operand.  UpFn's backward always runs before the pooling block's (the
+        decoder level sits above everything the pooling block feeds)."""
+
+    def __init__(self, up_channels):
+        self.up_channels = up_channels      # channels (padded when the net is padded) of the up-sampled half
+        self.buf = None
+        self.grad = None
+
+    def skip_view(self, n, c, d, h, w, dtype, device):
+        self.buf = N.new_act(n, self.up_channels + c, d, h, w, dtype, device)
+        return self.buf[:, self.up_channels:]
+
+
 # --------------------------------------------------------------------------- autograd: plain conv (stem / head / skip)
 def _f32_view(pack, count):
     """fp32 view of a ROLE_BIAS pack (the packs are 256-byte aligned slices of one uint8 allocation)."""
@@ -554,7 +576,10 @@ class ResBlockFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, ws, bs, stride, drop_scale, pad=0, checkpoint=False):
+    def forward(ctx, x, w1, b1, w2, b2, ws, bs, stride, drop_scale, pad=0, checkpoint=False, in_link=None,
+                out_link=None):
+        """in_link: SkipLink whose parked gradient this block adds to its input gradient (pooling block);
+        out_link: SkipLink into whose concat buffer the block writes its output (last encoder block of a level)."""
         sd = x.dtype
         x = N.to_ndhwc(x)
         cout, cin = w1.shape[0], w1.shape[1]
@@ -591,7 +616,14 @@ class ResBlockFn(torch.autograd.Function):
             skip = conv_fwd(x, packs[2], bs, cout_p, 1, stride)
         else:
             skip = x
-        z = in_lrelu_fwd(y2, mean2, scale2, res=skip)
+        n_, _, d_, h_, w_ = y2.shape
+        # in place only when a voxel's channels fill whole 128-byte lines of the interleaved [up | skip] buffer: at 32
+        # 16-bit channels every reader of the skip (pool conv, its weight gradient, the norm backward) would pull the
+        # other half's lines along - measured slower than the copy it saves
+        zout = None
+        if out_link is not None and cout_p * y2.element_size() >= 128:
+            zout = out_link.skip_view(n_, cout_p, d_, h_, w_, sd, x.device)
+        z = in_lrelu_fwd(y2, mean2, scale2, res=skip, out=zout)
         bwd = packs[nfwd:nw] + [None] * 3
         if checkpoint and train:
             ctx.save_for_backward(x, None, None, None, z, mean1, scale1, mean2, scale2, bwd[0], bwd[1], bwd[2],
@@ -602,6 +634,9 @@ class ResBlockFn(torch.autograd.Function):
         ctx.dims = (cout, cin, cout_seg, cin_seg)
         ctx.stride = stride
         ctx.has_skip_conv = ws is not None
+        ctx.in_link = in_link if (in_link is not None and ws is not None) else None
+        if in_link is not None:
+            in_link.fused_grad = ctx.in_link is not None and need_gx      # UpFn parks its share only when it will be used
         return z
 
     @staticmethod
@@ -639,12 +674,15 @@ class ResBlockFn(torch.autograd.Function):
         need_gx = ctx.needs_input_grad[0]
         if ctx.has_skip_conv:
             if need_gx:
-                gx0 = conv_dgrad(gpre, pwsd, tuple(x.shape), 1, stride)
+                parked = None
+                if ctx.in_link is not None:
+                    parked, ctx.in_link.grad = ctx.in_link.grad, None
+                gx0 = conv_dgrad(gpre, pwsd, tuple(x.shape), 1, stride, res=parked)
                 gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gx0)
         elif need_gx:
             gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gpre)
         _join(dev, gw1, gw2, gws, gbs)
-        return gx, gw1, gb1, gw2, gb2, gws, gbs, None, None, None, None
+        return gx, gw1, gb1, gw2, gb2, gws, gbs, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------- autograd: ConvTrans3D (+ concat)
@@ -657,7 +695,7 @@ class UpFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, wt, bt, skip, pad=False):
+    def forward(ctx, x, wt, bt, skip, pad=False, link=None):
         sd = x.dtype
         x = N.to_ndhwc(x)
         cin, cout = wt.shape[0], wt.shape[1]
@@ -681,10 +719,16 @@ class UpFn(torch.autograd.Function):
             cs = skip.shape[1]
             if tuple(skip.shape[2:]) != (d, h, w) or skip.shape[0] != n:
                 raise N.Ru3dError("UpConcat: skip %s does not match up-sampled %s" % (tuple(skip.shape), tuple(y.shape)))
-            buf = N.new_act(n, cout_p + cs, d, h, w, sd, x.device)
+            in_place = (link is not None and link.buf is not None and link.up_channels == cout_p
+                        and tuple(link.buf.shape) == (n, cout_p + cs, d, h, w) and link.buf.dtype == sd
+                        and skip.data_ptr() == link.buf[:, cout_p:].data_ptr())
+            buf = link.buf if in_place else N.new_act(n, cout_p + cs, d, h, w, sd, x.device)
             u = buf[:, :cout_p]
             in_lrelu_fwd(y, mean, scale, out=u)
-            copy_channels(skip, buf[:, cout_p:])
+            if not in_place:
+                copy_channels(skip, buf[:, cout_p:])
+            if link is not None:
+                link.buf = None          # the autograd graph owns the buffer from here on
             out = buf
         else:
             u = in_lrelu_fwd(y, mean, scale)
@@ -692,6 +736,7 @@ class UpFn(torch.autograd.Function):
         ctx.save_for_backward(x, y, out, mean, scale, packs[1] if ctx.needs_input_grad[0] else None)
         ctx.dims = (cout, cin, cout_seg, cin_seg)
         ctx.has_skip = skip is not None
+        ctx.link = link if (link is not None and getattr(link, "fused_grad", False)) else None
         return out
 
     @staticmethod
@@ -713,4 +758,6 @@ class UpFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = convt_dgrad(dy, pwd, tuple(x.shape))
         _join(x.device, gw, gb)
-        return gx, gw, gb, gskip, None
+        if ctx.link is not None and gskip is not None:
+            ctx.link.grad, gskip = gskip, None       # added by the pooling block's input-gradient kernel (SkipLink)
+        return gx, gw, gb, gskip, None, None

@@ -227,10 +227,11 @@ class ConvTrans3D(nn.Module):
         self._native = _is_plain_in(self.up[2]) and _is_plain_lrelu(self.up[3])
         self._pad = False          # set by Unet: activations carry channels zero-padded to multiples of 32
 
-    def forward(self, x, skip=None):
-        """`skip` is an extension used by UpConcat: returns cat((up(x), skip), dim=1) written in place."""
+    def forward(self, x, skip=None, link=None):
+        """`skip` is an extension used by UpConcat: returns cat((up(x), skip), dim=1) written in place.
+        `link`: ops.SkipLink of this skip connection (Unet passes it; see _ops.SkipLink)."""
         if self._native and x.is_cuda:
-            return ops.UpFn.apply(x, self.up[0].weight, self.up[0].bias, skip, self._pad)
+            return ops.UpFn.apply(x, self.up[0].weight, self.up[0].bias, skip, self._pad, link)
         if self._native:
             N.require_device(x, "ConvTrans3D input")
         y = self.up(x)
@@ -251,9 +252,9 @@ class UpConcat(nn.Module):
             self.att_gate = AttBlock(out_channels, conv_op=att_conv_op, nonlin_op=nonlin_op,
                                      nonlin_kwargs=nonlin_kwargs)
 
-    def forward(self, x, skip):
+    def forward(self, x, skip, link=None):
         if not self.attention and isinstance(self.conv_trans, ConvTrans3D):
-            return self.conv_trans(x, skip)          # up-sampled channels first, skip second
+            return self.conv_trans(x, skip, link)    # up-sampled channels first, skip second
         x = self.conv_trans(x)
         if self.attention:
             skip = self.att_gate(skip, x)
@@ -307,14 +308,16 @@ class ResBlock(nn.Module):
             return None
         return ops.dropout_scale(n, c, p, x.device)
 
-    def forward(self, x):
+    def forward(self, x, in_link=None, out_link=None):
+        """in_link / out_link: ops.SkipLink objects Unet passes to the pooling block / the last encoder block of a
+        level (see _ops.SkipLink); standalone use leaves them None."""
         if self._native and x.is_cuda:
             skip_w = self.skip_conv.weight if self.uses_skip_conv else None
             skip_b = self.skip_conv.bias if self.uses_skip_conv else None
             return ops.ResBlockFn.apply(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
                                         skip_w, skip_b, self.stride, self._drop_scale(x),
                                         self._in_segs if self._pad else 0,
-                                        self._checkpoint and torch.is_grad_enabled())
+                                        self._checkpoint and torch.is_grad_enabled(), in_link, out_link)
         if self._native:
             N.require_device(x, "ResBlock input")
         skip = self.skip_conv(x) if self.uses_skip_conv else x
@@ -340,9 +343,10 @@ class ResBlockStack(nn.Module):
             ResBlock(in_channels if i == 0 else out_channels, out_channels, stride=stride if i == 0 else 1,
                      **common) for i in range(num_stacks))
 
-    def forward(self, x):
-        for blk in self.res_blocks:
-            x = blk(x)
+    def forward(self, x, out_link=None):
+        last = len(self.res_blocks) - 1
+        for i, blk in enumerate(self.res_blocks):
+            x = blk(x, out_link=out_link) if (i == last and out_link is not None) else blk(x)
         return x
 
 
@@ -384,6 +388,7 @@ class Unet(nn.Module):
         self.compute_dtype = _DEFAULT_DTYPE
         self._native_io = _is_plain_conv3(self.conv) and _is_plain_conv1(self.fc)
         self._pad = False
+        self._linked = False
         self._configure_native()
 
     def _native_chain(self):
@@ -421,6 +426,10 @@ class Unet(nn.Module):
                and all(ops.cpad(c) * 2 <= 3 * c for c in widths)
                and os.environ.get("RU3D_PAD_CHANNELS", "1") != "0")
         self._pad = pad
+        # skip connections of an all-native net go through ops.SkipLink (no concat copy, no autograd add)
+        self._linked = (chain is not None and all(isinstance(b, (ResBlock, ResBlockStack)) for b in self.encode_blocks)
+                        and all(isinstance(b, ResBlock) and b.uses_skip_conv for b in self.pool_blocks)
+                        and os.environ.get("RU3D_SKIP_LINK", "1") != "0")
         for blk in (chain or []):
             blk._pad = pad
         for blk in self.decode_blocks:      # their input is cat((up, skip)): two padded segments
@@ -443,14 +452,22 @@ class Unet(nn.Module):
 
     def forward(self, x):
         x = self._stem(x)
-        skips = []
+        skips, links = [], []
+        linked = self._linked and x.is_cuda
         for i in range(self.num_pool):
-            x = self.encode_blocks[i](x)
+            link = None
+            if linked:
+                cu = self.up_blocks[i].conv_trans.out_channels
+                link = ops.SkipLink(ops.cpad(cu) if self._pad else cu)
+                x = self.encode_blocks[i](x, out_link=link)
+            else:
+                x = self.encode_blocks[i](x)
             skips.append(x)
-            x = self.pool_blocks[i](x)
+            links.append(link)
+            x = self.pool_blocks[i](x, in_link=link) if linked else self.pool_blocks[i](x)
         x = self.encode_blocks[-1](x)
         for i in reversed(range(self.num_pool)):
-            x = self.up_blocks[i](x, skips[i])
+            x = self.up_blocks[i](x, skips[i], links[i]) if linked else self.up_blocks[i](x, skips[i])
             x = self.decode_blocks[i](x)
         return self._head(x)
 
