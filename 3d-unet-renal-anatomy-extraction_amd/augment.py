@@ -167,3 +167,51 @@ class DeviceAugment:
             case = cases[int(self.rng.randint(0, len(cases)))]
             self.sample(case, x[b], y[b])
         return {"image": x, "label": y}
+
+
+# --------------------------------------------------------------------------- plain resampling (inference: predict_case)
+def _resample(image, label, out_shape):
+    """scipy.ndimage.zoom(order=1) of a whole device volume to `out_shape` with the augmentation kernel (crop box = the
+    volume, no mirror, no intensity ops): image fp32 [X,Y,Z,C] -> fp32 [C,x,y,z]; label [X,Y,Z] -> int64 [x,y,z] by the
+    reference's label rule (transform.py:47-74)."""
+    ref = image if image is not None else label
+    dev = ref.device
+    x, y, z = (int(v) for v in ref.shape[:3])
+    pr = N.PatchParams()
+    for i, (b, p) in enumerate(zip((x, y, z), out_shape)):
+        pr.lo[i], pr.before[i], pr.patch[i], pr.flip[i] = 0, b, int(p), 0
+    pr.gamma_eps = 1e-7
+    c = int(image.shape[3]) if image is not None else 1
+    out_image = torch.empty((c,) + tuple(int(p) for p in out_shape), dtype=torch.float32, device=dev) \
+        if image is not None else None
+    out_label = mask = None
+    code = N.LABEL_I64
+    if label is not None:
+        if label.dtype not in (torch.uint8, torch.int64):
+            label = label.to(torch.int64)
+        label = label.contiguous()
+        code = N.LABEL_U8 if label.dtype == torch.uint8 else N.LABEL_I64
+        out_label = torch.empty(tuple(int(p) for p in out_shape), dtype=torch.int64, device=dev)
+        mask = torch.empty(1, dtype=torch.int32, device=dev)
+        lo_a = (ctypes.c_int32 * 3)(0, 0, 0)
+        be_a = (ctypes.c_int32 * 3)(x, y, z)
+        N.note_device(dev)
+        check(N.lib.ru3d_augment_label_presence(ptr(label), code, x, y, z, lo_a, be_a, 0, ptr(mask), stream()),
+              "augment_label_presence")
+    ws = N.workspace(N.lib.ru3d_augment_workspace_bytes(*[int(p) for p in out_shape]), dev)
+    N.note_device(dev)
+    check(N.lib.ru3d_augment_patch(ptr(image), ptr(label), code, x, y, z, c, ctypes.byref(pr), ptr(mask),
+                                   ptr(out_image), ptr(out_label), ptr(ws), ws.numel(), stream()), "augment_patch")
+    return out_image, out_label
+
+
+def resample_image(image, out_shape):
+    """fp32 device volume [X,Y,Z,C] -> [x,y,z,C] (channels last again), every channel zoomed with order 1."""
+    out, _ = _resample(image.to(torch.float32).contiguous(), None, out_shape)
+    return out.permute(1, 2, 3, 0).contiguous()
+
+
+def resample_label(label, out_shape):
+    """integer device volume [X,Y,Z] -> int64 [x,y,z] (one-hot / argmax rule for three or more classes)."""
+    _, out = _resample(None, label, out_shape)
+    return out

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
             src[k] = in ? ((int64_t)gx * Y + gy) * Z + gz : -1;
         }
         // separable order of scipy's zoom: axis 0 first, then 1, then 2 (each a float64 lerp)
-        for (int c = 0; c < C; c++) {
+        for (int c = 0; image && c < C; c++) {
             double v[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) v[k] = src[k] >= 0 ? (double)image[src[k] * C + c] : (double)image_cval;
@@ -261,8 +261,10 @@ extern "C" int ru3d_augment_patch(const float* image, const void* label, int lab
                                   const ru3d_patch_params* p, const uint32_t* presence_mask, float* out_image,
                                   int64_t* out_label, void* ws, size_t ws_bytes, void* stream) {
     Ru3dDeviceGuard dev_guard(stream);
-    RU3D_REQUIRE(image && p && out_image && ws && X > 0 && Y > 0 && Z > 0 && C > 0, "augment_patch: bad argument");
+    RU3D_REQUIRE(p && ws && X > 0 && Y > 0 && Z > 0 && C > 0, "augment_patch: bad argument");
+    RU3D_REQUIRE((image == nullptr) == (out_image == nullptr), "augment_patch: image and out_image go together");
     RU3D_REQUIRE((label == nullptr) == (out_label == nullptr), "augment_patch: label and out_label go together");
+    RU3D_REQUIRE(image || label, "augment_patch: nothing to resample");
     for (int d = 0; d < 3; d++)
         RU3D_REQUIRE(p->before[d] > 0 && p->patch[d] > 0, "augment_patch: empty crop box / patch on axis %d", d);
     RU3D_REQUIRE(ws_bytes >= ru3d_augment_workspace_bytes(p->patch[0], p->patch[1], p->patch[2]),
@@ -287,7 +289,7 @@ extern "C" int ru3d_augment_patch(const float* image, const void* label, int lab
         return ru3d_fail(-1, "augment_patch: bad label dtype %d", label_dtype);
     int rc = ru3d_check_launch("augment_resample");
     if (rc) return rc;
-    if (!(p->do_contrast || p->do_brightness || p->do_gamma)) return 0;
+    if (!image || !(p->do_contrast || p->do_brightness || p->do_gamma)) return 0;
     const int64_t count = total * C;
     int64_t ib = (count + 1023) / 1024;
     if (ib > 512) ib = 512;

@@ -73,16 +73,19 @@ def window_origins(shape, patch_size, step_per_patch):
 
 
 def predict_per_patch(input, model, num_classes=3, patch_size=(96, 96, 96), step_per_patch=4, verbose=True,
-                      one_hot=False, patch_batch=1):
-    """input: numpy [X, Y, Z, C_in] (the reference's W,H,D,C case layout).  Returns the uint8 mask [X, Y, Z]
-    (or the float32 [X, Y, Z, num_classes] probability map when one_hot) at the input's own shape."""
+                      one_hot=False, patch_batch=1, return_device=False):
+    """input: numpy (or torch, host or device) [X, Y, Z, C_in] (the reference's W,H,D,C case layout).  Returns the
+    uint8 mask [X, Y, Z] (or the float32 [X, Y, Z, num_classes] probability map when one_hot) at the input's own shape,
+    as a numpy array like the reference - or as the device tensor when return_device (predict_case keeps going on
+    the GPU)."""
     device = next(model.parameters()).device
     N.require_device(next(model.parameters()), "model")
     patch_size = tuple(int(p) for p in patch_size)
     if any(p % 2 for p in patch_size):
         # the reference slices [c - p//2, c + p//2): an odd patch would feed the model p-1 voxels
         raise ValueError("predict_per_patch: patch_size must be even, got %s" % (patch_size,))
-    input = np.asarray(input)
+    if not torch.is_tensor(input):
+        input = np.asarray(input)
     if input.ndim != 4:
         raise ValueError("predict_per_patch: expected a [X, Y, Z, C] volume, got shape %s" % (input.shape,))
     original_shape = tuple(int(s) for s in input.shape[:3])
@@ -94,7 +97,8 @@ def predict_per_patch(input, model, num_classes=3, patch_size=(96, 96, 96), step
     # padded volume in HBM, NDHWC (= the case layout with a leading batch axis); zero padding as np.pad's default
     vol = torch.zeros((1,) + full + (cin,), dtype=torch.float32, device=device)
     vol[0, lo[0]:lo[0] + original_shape[0], lo[1]:lo[1] + original_shape[1], lo[2]:lo[2] + original_shape[2]] = \
-        torch.from_numpy(np.ascontiguousarray(input, dtype=np.float32)).to(device)
+        (input.to(device=device, dtype=torch.float32) if torch.is_tensor(input)
+         else torch.from_numpy(np.ascontiguousarray(input, dtype=np.float32)).to(device))
     vol = vol.permute(0, 4, 1, 2, 3)                                   # [1, C, X, Y, Z] view
 
     origins, counts = window_origins(full, patch_size, step_per_patch)
@@ -142,4 +146,50 @@ def predict_per_patch(input, model, num_classes=3, patch_size=(96, 96, 96), step
     N.note_device(acc.device)
     check(N.lib.ru3d_predict_merge(ptr(acc), ptr(cnt), full[0], full[1], full[2], num_classes, co[0], co[1], co[2],
                                    sx, sy, sz, 1 if one_hot else 0, ptr(out), stream()), "predict_merge")
-    return out.cpu().numpy()
+    return out if return_device else out.cpu().numpy()
+
+
+# --------------------------------------------------------------------------- whole-case inference (trainer.py:101-133)
+def _zoomed_shape(shape, scale):
+    """Output shape of scipy.ndimage.zoom for an input shape and per-axis factors."""
+    return tuple(int(round(s * z)) for s, z in zip(shape, scale))
+
+
+def predict_case(case, model, target_spacing, normalize_stats, num_classes=3, patch_size=(96, 96, 96),
+                 step_per_patch=4, verbose=True, one_hot=False, patch_batch=1):
+    """reference trainer.py:101-133: resample the case to `target_spacing` and normalise it (data.py:222-283), run the
+    sliding-window prediction, resize the prediction back to the case's shape.  Everything between the upload of the
+    image and the download of the prediction runs on the device: the two resamplings are the order-1 zoom kernel of
+    the augmentation path (label rule included), the sliding window is predict_per_patch."""
+    import augment
+    device = next(model.parameters()).device
+    image = np.asarray(case['image'])
+    if image.ndim == 3:
+        image = image[..., None]
+    orig_shape = tuple(int(s) for s in image.shape[:-1])
+    affine = np.asarray(case['affine'], dtype=np.float64)
+    stats = normalize_stats if isinstance(normalize_stats, list) else [normalize_stats]
+    if verbose:
+        print('Resampling the case for prediction...')
+    spacing = np.array([np.linalg.norm(affine[i, :3]) for i in range(3)])
+    scale = spacing / np.array(target_spacing, dtype=np.float64)
+    vol = torch.from_numpy(np.ascontiguousarray(image, dtype=np.float32)).to(device)
+    vol = augment.resample_image(vol, _zoomed_shape(orig_shape, scale))
+    for c, s in enumerate(stats):                 # clip to the percentiles, then (x - mean) / (std + 1e-8)
+        vol[..., c].clamp_(float(s['pct_00_5']), float(s['pct_99_5'])).sub_(float(s['mean'])).div_(float(s['std']) + 1e-8)
+    vol = vol[..., :len(stats)]
+    if verbose:
+        print('Predicting the case...')
+    pred = predict_per_patch(vol, model, num_classes, patch_size, step_per_patch, verbose, one_hot,
+                             patch_batch=patch_batch, return_device=True)
+    if verbose:
+        print('Resizing the case to origial shape...')
+    if one_hot:
+        out = augment.resample_image(pred, orig_shape).cpu().numpy()
+    else:
+        out = augment.resample_label(pred, orig_shape).to(torch.uint8).cpu().numpy()
+    case['pred'] = out
+    case['affine'] = affine
+    if verbose:
+        print('All done!')
+    return case

@@ -37,7 +37,7 @@ except Exception:
     SummaryWriter = None
 
 from loss import dice  # noqa: F401  (re-exported like the reference: trainer.dice)
-from inference import predict_per_patch  # noqa: F401  (reference trainer.py:17)
+from inference import predict_per_patch, predict_case  # noqa: F401  (reference trainer.py:17, 101)
 
 
 class _NullBar:
@@ -405,3 +405,89 @@ class Trainer():
     # run_train.py spelling
     save = save_checkpoint
     load = load_checkpoint
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Case-level drivers around predict_case (reference trainer.py:136-400): host glue, the arithmetic is in inference.py.
+def batch_predict_case(load_dir, save_dir, model, target_spacing, normalize_stats, num_classes=3,
+                       patch_size=(240, 240, 80), step_per_patch=4, data_range=None):
+    """trainer.py:136-161"""
+    from data import CaseDataset, save_pred
+    cases = CaseDataset(load_dir)
+    for i in (data_range if data_range is not None else range(len(cases))):
+        case = predict_case(cases[i], model, target_spacing, normalize_stats, num_classes, patch_size,
+                            step_per_patch, False)
+        save_pred(case, save_dir)
+
+
+def cascade_predict_case(case, coarse_model, coarse_target_spacing, coarse_normalize_stats, coarse_patch_size,
+                         detail_model, detail_target_spacing, detail_normalize_stats, detail_patch_size,
+                         num_classes=3, step_per_patch=4, region_threshold=10000, crop_padding=20, verbose=True):
+    """trainer.py:164-245: a single-class coarse pass finds the regions of interest, the detail model predicts class
+    probabilities inside each (padded) region, the regions' maps are averaged where they overlap and arg-maxed."""
+    from data import regions_crop_case
+    if verbose:
+        print('Predicting the rough shape for further prediction...')
+    case = predict_case(case, coarse_model, coarse_target_spacing, coarse_normalize_stats, 1, coarse_patch_size,
+                        step_per_patch, verbose=verbose)
+    regions = regions_crop_case(case, region_threshold, crop_padding, 'pred')
+    num_classes = detail_model.out_channels
+    orig_shape = case['image'].shape[:-1]
+    total = np.zeros(list(orig_shape) + [num_classes])
+    hits = np.zeros_like(total)
+    if verbose:
+        print('Cropping regions (%d)...' % len(regions))
+    for idx, region in enumerate(regions):
+        bbox, shape = region['bbox'], region['image'].shape[:-1]
+        if verbose:
+            print('Region {} {} predicting...'.format(idx, shape))
+        region = predict_case(region, detail_model, detail_target_spacing, detail_normalize_stats, num_classes,
+                              detail_patch_size, step_per_patch, verbose=verbose, one_hot=True)
+        inside = tuple(slice(max(-bbox[d][0], 0), shape[d] - max(bbox[d][1] - orig_shape[d], 0)) for d in range(3))
+        target = tuple(slice(max(bbox[d][0], 0), min(bbox[d][1], orig_shape[d])) for d in range(3))
+        total[target] += region['pred'][inside]
+        hits[target] += 1
+    if verbose:
+        print('Merging all regions...')
+    seen = hits > 0
+    total[seen] = total[seen] / hits[seen]
+    if num_classes == 1:
+        merged = np.around(np.squeeze(total, axis=-1))
+    else:
+        e = np.exp(total - total.max(axis=-1, keepdims=True))      # scipy.special.softmax, then argmax
+        merged = np.argmax(e / e.sum(axis=-1, keepdims=True), axis=-1)
+    case['pred'] = merged.astype(np.uint8)
+    if verbose:
+        print('All done!')
+    return case
+
+
+def evaluate_case(case):
+    """trainer.py:348-356: Dice (loss.dice, alpha = beta = 0.5) of every foreground class of label vs pred."""
+    out = []
+    for c in range(int(case['label'].max())):
+        p = np.array(case['pred'] == c + 1).astype(np.float32)
+        g = np.array(case['label'] == c + 1).astype(np.float32)
+        out.append(dice(torch.tensor(p), torch.tensor(g)).item())
+    return out
+
+
+def evaluate(label_file, pred_file):
+    """trainer.py:359-368"""
+    import nifti
+    label, _, _ = nifti.load(label_file)
+    pred, _, _ = nifti.load(pred_file)
+    return evaluate_case({'label': label.astype(np.uint8), 'pred': pred.astype(np.uint8)})
+
+
+def batch_evaluate(label_dir, pred_dir, data_range=None):
+    """trainer.py:371-400"""
+    from pathlib import Path
+    label_files = sorted(Path(label_dir).glob('*.nii.gz'))
+    pred_files = sorted(Path(pred_dir).glob('*.nii.gz'))
+    results = [evaluate(label_files[i], pred_files[i])
+               for i in (data_range if data_range is not None else range(len(label_files)))]
+    print('\nThe mean dsc of each label:')
+    for i, m in enumerate(np.array(results).mean(axis=0)):
+        print("label_%d: %f" % (i + 1, m))
+    return results

@@ -234,7 +234,7 @@ size_t ru3d_augment_workspace_bytes(int px, int py, int pz);
 /* mask (1 device uint32): bit min(v, 31) set for every label value v inside the crop box (pad value included). */
 int ru3d_augment_label_presence(const void* label, int label_dtype, int X, int Y, int Z, const int32_t* lo,
                                 const int32_t* before, int label_cval, uint32_t* mask, void* stream);
-/* label / out_label may both be NULL (image only).  presence_mask: device uint32 from the call above (the label rule
+/* label / out_label may both be NULL (image only), or image / out_image (label only).  presence_mask: device uint32 from the call above (the label rule
  * of transform.py:47-48 needs the number of classes in the crop); NULL = treat as >= 3 classes. */
 int ru3d_augment_patch(const float* image, const void* label, int label_dtype, int X, int Y, int Z, int C,
                        const ru3d_patch_params* p, const uint32_t* presence_mask, float* out_image, int64_t* out_label,

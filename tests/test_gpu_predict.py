@@ -188,3 +188,36 @@ def test_packed_weight_cache_follows_weight_updates():
     with torch.no_grad():
         f = other(x).clone()
     assert torch.equal(f, d)
+
+
+# --------------------------------------------------------------------------- whole-case inference (trainer.py:101-133)
+def test_predict_case_device_pipeline_vs_host_composition():
+    """trainer.predict_case (resample + normalise + sliding window + resize, all on the device) against the same chain
+    assembled from the host-side pieces the reference uses: data.resample_normalize_case (scipy zoom),
+    predict_per_patch, transform.resize (scipy zoom, label rule)."""
+    import data
+    import network
+    import trainer
+    import transform as T
+    torch.manual_seed(3)
+    model = network.ResUnet3D(2, 8, 1, 3).to(DEV).eval()
+    rng = np.random.RandomState(5)
+    g = np.meshgrid(*[np.linspace(-1, 1, s) for s in (44, 40, 20)], indexing="ij")
+    img = (80 * np.sin(3 * g[0]) * np.cos(2 * g[1]) + 60 * g[2] + 100 + 5 * rng.randn(44, 40, 20)).astype(np.float32)
+    case = {"case_id": "c", "affine": np.diag([1.5, 1.5, 3.0, 1.0]), "image": img[..., None]}
+    stats = {"mean": 100.0, "std": 60.0, "pct_00_5": -50.0, "pct_99_5": 250.0}
+    spacing, patch = (1.0, 1.2, 2.0), (32, 32, 16)
+    for one_hot in (False, True):
+        got = trainer.predict_case(dict(case), model, spacing, stats, num_classes=3, patch_size=patch,
+                                   step_per_patch=2, verbose=False, one_hot=one_hot)["pred"]
+        rs = data.resample_normalize_case(case, spacing, stats)
+        ref = trainer.predict_per_patch(rs["image"].astype(np.float32), model, 3, patch, 2, False, one_hot)
+        want = T.resize(ref, case["image"].shape[:-1], is_label=one_hot is False)
+        assert got.shape == want.shape
+        if one_hot:
+            ok = np.isfinite(want)
+            assert np.array_equal(ok, np.isfinite(got))
+            assert np.abs(got[ok] - want[ok]).max() <= 2e-4
+        else:
+            assert got.dtype == np.uint8
+            assert (got != want).mean() <= 2e-3          # interpolation ulps can move a voxel that sits on a tie
