@@ -72,6 +72,7 @@ SIGNATURES = {
     "ru3d_in_lrelu_bwd": (_i, [_P, _P, _P, _vp, _vp, _P, _P, _vp, _sz, _f, _i, _vp, _i, _vp]),
     "ru3d_channel_sum": (_i, [_P, _vp, _vp, _sz, _i, _vp]),
     "ru3d_dropout3d_scale": (_i, [_vp, _i, _f, _u64, _u64, _vp]),
+    "ru3d_pointwise": (_i, [_i, _P, _P, _P, _P, _P, _f, _i, _vp]),
     "ru3d_copy_channels": (_i, [_P, _P, _i, _vp]),
     "ru3d_add": (_i, [_P, _P, _P, _i, _vp]),
     "ru3d_cast_f32": (_i, [_P, _P, _i, _vp]),

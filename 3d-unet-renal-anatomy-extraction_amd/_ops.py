@@ -344,6 +344,20 @@ def channel_sum(t):
     return out
 
 
+def pointwise(op, a, b=None, c=None, n_out=1):
+    """ru3d_pointwise (the attention gate's elementwise pieces): returns o1 or (o1, o2)."""
+    n, ch, d, h, w = a.shape
+    o1 = N.new_act(n, ch, d, h, w, a.dtype, a.device)
+    o2 = N.new_act(n, ch, d, h, w, a.dtype, a.device) if n_out == 2 else None
+    da, d1 = desc(a), desc(o1)
+    db = desc(b) if b is not None else None
+    dc = desc(c) if c is not None else None
+    d2 = desc(o2) if o2 is not None else None
+    check(N.lib.ru3d_pointwise(op, ref(da), ref(db), ref(dc), ref(d1), ref(d2), LRELU_SLOPE, N.dtype_code(a.dtype),
+                               stream()), "pointwise")
+    return (o1, o2) if n_out == 2 else o1
+
+
 def copy_channels(src, dst):
     ds, dd = desc(src), desc(dst)
     check(N.lib.ru3d_copy_channels(ref(ds), ref(dd), N.dtype_code(src.dtype), stream()), "copy_channels")
@@ -761,3 +775,60 @@ class UpFn(torch.autograd.Function):
         if ctx.link is not None and gskip is not None:
             ctx.link.grad, gskip = gskip, None       # added by the pooling block's input-gradient kernel (SkipLink)
         return gx, gw, gb, gskip, None, None
+
+
+# --------------------------------------------------------------------------- autograd: attention gate (+ concat)
+class AttGateFn(torch.autograd.Function):
+    """reference network.py:365-371 (AttBlock.forward) followed by network.py:350 (cat((up, gated_skip), dim=1)):
+        x = conv(skip); g = conv(up); rate = sigmoid(conv(lrelu(x + g))); out = cat((up, x * rate))
+    with ONE shared 1x1x1 convolution (weight [C, C, 1, 1, 1], bias).  The three convolutions and their gradients
+    run on the conv kernels, the elementwise pieces on ru3d_pointwise; the weight gradient is the sum of the three
+    uses.  pad: channel-padded activations (see ResBlockFn)."""
+
+    @staticmethod
+    def forward(ctx, skip, up, w, b, pad=False):
+        sd = up.dtype
+        skip = as_grad(skip, sd)
+        up = N.to_ndhwc(up)
+        c = w.shape[0]
+        seg = c if pad else 0
+        cp = padded_dim(c, seg)
+        if skip.shape[1] != cp or up.shape[1] != cp:
+            raise N.Ru3dError("AttBlock: skip %s / gate %s do not carry %d channels" % (tuple(skip.shape), tuple(up.shape), cp))
+        specs = [(w, N.ROLE_CONV_FWD, 1, seg, seg), (w, N.ROLE_CONV_DGRAD, 1, seg, seg)]
+        if seg and b is not None:
+            specs.append((b, N.ROLE_BIAS, 1, seg, 0))
+        packs = pack_weights(specs, sd)
+        bp = _f32_view(packs[-1], cp) if (seg and b is not None) else b
+        xs = conv_fwd(skip, packs[0], bp, cp, 1, 1)
+        t = conv_fwd(up, packs[0], bp, cp, 1, 1, res=xs)          # conv(up) + b + x
+        f = pointwise(0, t)
+        del t
+        r = conv_fwd(f, packs[0], bp, cp, 1, 1)
+        gated = pointwise(1, xs, r)
+        n, _, d, h, wd = up.shape
+        out = N.new_act(n, 2 * cp, d, h, wd, sd, up.device)
+        copy_channels(up, out[:, :cp])
+        copy_channels(gated, out[:, cp:])
+        ctx.save_for_backward(skip, up, xs, f, r, packs[1])
+        ctx.dims = (c, seg, cp, b is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        skip, up, xs, f, r, pwd = ctx.saved_tensors
+        c, seg, cp, has_bias = ctx.dims
+        sd = up.dtype
+        g = as_grad(g, sd)
+        g_up_direct, g_gated = g[:, :cp], g[:, cp:]
+        dxs1, dr = pointwise(2, xs, r, g_gated, n_out=2)
+        d_f = conv_dgrad(dr, pwd, tuple(f.shape), 1, 1)
+        d_t, d_xs = pointwise(3, f, dxs1, d_f, n_out=2)              # d_t = d_f * lrelu'(f); d_xs = d_t + dxs1
+        gw = conv_wgrad(f, dr, 1, 1) + conv_wgrad(up, d_t, 1, 1) + conv_wgrad(skip, d_xs, 1, 1)
+        gw = unpad_wgrad(gw, c, c, seg, seg)
+        gb = None
+        if has_bias:
+            gb = (channel_sum(dr) + channel_sum(d_t) + channel_sum(d_xs))[:c]
+        g_up = conv_dgrad(d_t, pwd, tuple(up.shape), 1, 1, res=g_up_direct)
+        g_skip = conv_dgrad(d_xs, pwd, tuple(skip.shape), 1, 1)
+        return g_skip, g_up, gw, gb, None

@@ -25,7 +25,8 @@
     X(ru3d_add) \
     X(ru3d_cast_f32) \
     X(ru3d_ncdhw_to_ndhwc) \
-    X(ru3d_ndhwc_to_ncdhw)
+    X(ru3d_ndhwc_to_ncdhw) \
+    X(ru3d_pointwise)
 
 #ifdef RU3D_STORAGE_F16
 #define ru3d_packed_weight_bytes ru3d_packed_weight_bytes_f16
@@ -51,4 +52,5 @@
 #define ru3d_cast_f32 ru3d_cast_f32_f16
 #define ru3d_ncdhw_to_ndhwc ru3d_ncdhw_to_ndhwc_f16
 #define ru3d_ndhwc_to_ncdhw ru3d_ndhwc_to_ncdhw_f16
+#define ru3d_pointwise ru3d_pointwise_f16
 #endif

@@ -352,6 +352,49 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(const T* __restrict__
     }
 }
 
+// --------------------------------------------------------------------------- attention gate pointwise ops
+// AttBlock (reference network.py:353-371): x = conv(x); g = conv(gate); rate = sigmoid(conv(lrelu(x + g))); x * rate.
+// The three 1x1x1 convolutions run on the conv kernels; these are the elementwise pieces in between and their
+// gradients.  OP: 0 o1 = lrelu(a)   1 o1 = a * sigmoid(b)   2 (o1, o2) = (c * sigmoid(b), c * a * sigmoid'(b))
+//             3 (o1, o2) = (c * lrelu'(a), c * lrelu'(a) + b)       (a is the lrelu OUTPUT: its sign is the input's)
+template <typename T, int VEC, int OP>
+__global__ __launch_bounds__(256) void pointwise_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b, int ldb,
+                                                        const T* __restrict__ c, int ldc, T* __restrict__ o1, int ld1,
+                                                        T* __restrict__ o2, int ld2, float slope, ChanLoop cl) {
+    const int tid = threadIdx.x;
+    const int cgl = tid % cl.Gb, vl = tid / cl.Gb;
+    const int cg = blockIdx.z * cl.Gb + cgl;
+    const int n = blockIdx.y;
+    if (vl >= cl.vpb || cg >= cl.G) return;
+    const int v0 = blockIdx.x * cl.span;
+    int v1 = v0 + cl.span;
+    if (v1 > cl.V) v1 = cl.V;
+    for (int v = v0 + vl; v < v1; v += cl.vpb) {
+        const int64_t row = (int64_t)n * cl.V + v;
+        float av[VEC], bv[VEC], cv[VEC], r1[VEC], r2[VEC];
+        load_vec<T, VEC>(a + row * lda + cg * VEC, av);
+        if (OP >= 1) load_vec<T, VEC>(b + row * ldb + cg * VEC, bv);
+        if (OP >= 2) load_vec<T, VEC>(c + row * ldc + cg * VEC, cv);
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+            if (OP == 0) {
+                r1[i] = lrelu_f(av[i], slope);
+            } else if (OP == 1) {
+                r1[i] = av[i] / (1.f + __expf(-bv[i]));
+            } else if (OP == 2) {
+                const float sg = 1.f / (1.f + __expf(-bv[i]));
+                r1[i] = cv[i] * sg;
+                r2[i] = cv[i] * av[i] * sg * (1.f - sg);
+            } else {
+                r1[i] = av[i] > 0.f ? cv[i] : cv[i] * slope;
+                r2[i] = r1[i] + bv[i];
+            }
+        }
+        store_vec<T, VEC>(o1 + row * ld1 + cg * VEC, r1);
+        if (OP >= 2) store_vec<T, VEC>(o2 + row * ld2 + cg * VEC, r2);
+    }
+}
+
 // dst = a (+ b)
 template <typename T, int VEC, bool ADD>
 __global__ __launch_bounds__(256) void copy_add_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b,
@@ -588,6 +631,43 @@ static int copy_add_impl(const ru3d_tensor* a, const ru3d_tensor* b, const ru3d_
     DISPATCH_VEC(T, vec, CALL)
 #undef CALL
     return ru3d_check_launch("copy_add");
+}
+
+template <typename T>
+static int pointwise_impl(int op, const ru3d_tensor* a, const ru3d_tensor* b, const ru3d_tensor* c, const ru3d_tensor* o1,
+                          const ru3d_tensor* o2, float slope, hipStream_t st) {
+    const int64_t V = (int64_t)a->d * a->h * a->w;
+    const int vec = pick_vec<T>(a->c, {a, b, c, o1, o2});
+    ChanLoop cl = make_chanloop(V, a->c, vec, 16, a->n);
+    dim3 grid(cl.chunks, a->n, (cl.G + cl.Gb - 1) / cl.Gb);
+#define PW(TT, VV, OPV)                                                                                                \
+    hipLaunchKernelGGL((pointwise_kernel<TT, VV, OPV>), grid, dim3(256), 0, st, (const TT*)a->ptr, a->ld,                \
+                       (const TT*)(b ? b->ptr : nullptr), b ? b->ld : 0, (const TT*)(c ? c->ptr : nullptr),              \
+                       c ? c->ld : 0, (TT*)o1->ptr, o1->ld, (TT*)(o2 ? o2->ptr : nullptr), o2 ? o2->ld : 0, slope, cl)
+#define CALL(TT, VV)              \
+    if (op == 0) PW(TT, VV, 0);   \
+    else if (op == 1) PW(TT, VV, 1); \
+    else if (op == 2) PW(TT, VV, 2); \
+    else PW(TT, VV, 3)
+    DISPATCH_VEC(T, vec, CALL)
+#undef CALL
+#undef PW
+    return ru3d_check_launch("pointwise");
+}
+
+extern "C" int ru3d_pointwise(int op, const ru3d_tensor* a, const ru3d_tensor* b, const ru3d_tensor* c,
+                              const ru3d_tensor* o1, const ru3d_tensor* o2, float slope, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_pointwise_f16(op, a, b, c, o1, o2, slope, dtype, stream));
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(op >= 0 && op <= 3, "pointwise: bad op %d", op);
+    RU3D_REQUIRE(tensor_ok(a) && tensor_ok(o1) && same_shape(a, o1), "pointwise: bad a / o1");
+    RU3D_REQUIRE(op < 1 || (tensor_ok(b) && same_shape(a, b)), "pointwise: op %d needs b", op);
+    RU3D_REQUIRE(op < 2 || (tensor_ok(c) && same_shape(a, c) && tensor_ok(o2) && same_shape(a, o2)),
+                 "pointwise: op %d needs c and o2", op);
+    RU3D_REQUIRE((int64_t)a->d * a->h * a->w < (1ll << 31), "pointwise: sample too large");
+    if (dtype == RU3D_F32) return pointwise_impl<float>(op, a, b, c, o1, o2, slope, as_stream(stream));
+    if (dtype == RU3D_BF16) return pointwise_impl<bf16>(op, a, b, c, o1, o2, slope, as_stream(stream));
+    return ru3d_fail(-1, "pointwise: bad dtype %d", dtype);
 }
 
 extern "C" int ru3d_copy_channels(const ru3d_tensor* src, const ru3d_tensor* dst, int dtype, void* stream) {

@@ -186,13 +186,15 @@ class ResRecBlock(nn.Module):
 
 
 class AttBlock(nn.Module):
-    """Attention gate sharing one 1x1 conv (torch ops)."""
+    """Attention gate sharing one 1x1 conv (reference network.py:353-371).  Inside a native UpConcat it runs as
+    ops.AttGateFn (conv kernels + ru3d_pointwise); called on its own it is the plain torch composition."""
 
     def __init__(self, out_channels, conv_op=nn.Conv3d, nonlin_op=nn.LeakyReLU, nonlin_kwargs={'inplace': True}):
         super().__init__()
         self.conv = conv_op(out_channels, out_channels, kernel_size=1)
         self.lrelu = nonlin_op(**nonlin_kwargs)
         self.active = nn.Sigmoid()
+        self._native = _is_plain_conv1(self.conv) and self.conv.stride == (1, 1, 1) and _is_plain_lrelu(self.lrelu)
 
     def forward(self, x, gate):
         x = self.conv(x)
@@ -255,6 +257,11 @@ class UpConcat(nn.Module):
     def forward(self, x, skip, link=None):
         if not self.attention and isinstance(self.conv_trans, ConvTrans3D):
             return self.conv_trans(x, skip, link)    # up-sampled channels first, skip second
+        if (self.attention and isinstance(self.conv_trans, ConvTrans3D) and self.conv_trans._native
+                and self.att_gate._native and x.is_cuda):
+            up = self.conv_trans(x)
+            return ops.AttGateFn.apply(skip, up, self.att_gate.conv.weight, self.att_gate.conv.bias,
+                                       self.conv_trans._pad)
         x = self.conv_trans(x)
         if self.attention:
             skip = self.att_gate(skip, x)
@@ -403,8 +410,8 @@ class Unet(nn.Module):
             if not (isinstance(blk, ResBlock) and blk._native):
                 return None
         for up in self.up_blocks:
-            if not (isinstance(up, UpConcat) and not up.attention and isinstance(up.conv_trans, ConvTrans3D)
-                    and up.conv_trans._native):
+            if not (isinstance(up, UpConcat) and isinstance(up.conv_trans, ConvTrans3D) and up.conv_trans._native
+                    and (not up.attention or up.att_gate._native)):
                 return None
             blocks.append(up.conv_trans)
         return blocks if self._native_io else None
@@ -427,7 +434,8 @@ class Unet(nn.Module):
                and os.environ.get("RU3D_PAD_CHANNELS", "1") != "0")
         self._pad = pad
         # skip connections of an all-native net go through ops.SkipLink (no concat copy, no autograd add)
-        self._linked = (chain is not None and all(isinstance(b, (ResBlock, ResBlockStack)) for b in self.encode_blocks)
+        self._linked = (chain is not None and not any(getattr(up, "attention", False) for up in self.up_blocks)
+                        and all(isinstance(b, (ResBlock, ResBlockStack)) for b in self.encode_blocks)
                         and all(isinstance(b, ResBlock) and b.uses_skip_conv for b in self.pool_blocks)
                         and os.environ.get("RU3D_SKIP_LINK", "1") != "0")
         for blk in (chain or []):
@@ -500,7 +508,7 @@ class ResUnet3D(_UnetWrapper):
 
 
 class ResAttrUnet3D(_UnetWrapper):
-    """ResUnet3D with attention-gated skips (attention gate runs as torch ops)."""
+    """ResUnet3D with attention-gated skips (the gate runs on the conv kernels + ru3d_pointwise: ops.AttGateFn)."""
 
     def __init__(self, num_pool=4, num_features=30, in_channels=1, out_channels=1):
         super().__init__()

@@ -165,6 +165,14 @@ int ru3d_channel_sum(const ru3d_tensor* t, float* out, void* ws, size_t ws_bytes
  * counter-based RNG keyed by (seed, offset). */
 int ru3d_dropout3d_scale(float* scale, int count, float p, uint64_t seed, uint64_t offset, void* stream);
 
+/* Elementwise pieces of the attention gate (AttBlock, network.py:353-371: x = conv(x); g = conv(gate);
+ * rate = sigmoid(conv(lrelu(x + g))); return x * rate) and of its backward; the convolutions are ru3d_conv3d_*.
+ *   op 0: o1 = lrelu(a)                                  op 1: o1 = a * sigmoid(b)
+ *   op 2: o1 = c * sigmoid(b),  o2 = c * a * sigmoid'(b)  (c = upstream gradient, a = gated tensor, b = pre-sigmoid)
+ *   op 3: o1 = c * lrelu'(a),   o2 = o1 + b               (a = the lrelu OUTPUT, c = its gradient, b = another share) */
+int ru3d_pointwise(int op, const ru3d_tensor* a, const ru3d_tensor* b, const ru3d_tensor* c, const ru3d_tensor* o1,
+                   const ru3d_tensor* o2, float slope, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ layout helpers ---------- */
 /* dst[...,c] = src[...,c] for c < src.c (torch.cat along channels, network.py:350, written in place). */
 int ru3d_copy_channels(const ru3d_tensor* src, const ru3d_tensor* dst, int dtype, void* stream);
