@@ -207,6 +207,12 @@ static int run_conv(const ru3d_tensor* x, const void* w, const float* bias, cons
     if (!bias && head_dgrad_eligible(g, dtype, y_dtype, res)) return head_dgrad_launch(x->ptr, w, y->ptr, g, dtype, st);
     if (mfma_conv_eligible(g.Cin, g.Cout, k, dtype, y_dtype) && mfma_conv_geometry_ok(g))
         return conv_mfma_launch(x->ptr, w, bias, res ? res->ptr : nullptr, y->ptr, g, st, nullptr, ws, ws_bytes);
+    // ru3d_pack_weight(s) chose the MFMA fragment layout from (channels, k, dtype) alone: a conv of such a shape that
+    // cannot take the MFMA path (16-bit input with an fp32 output other than the small head) must not hand that pack to
+    // the direct kernel, which expects [tap][cin][cout_pad]
+    if (mfma_conv_eligible(g.Cin, g.Cout, k, dtype, dtype))
+        return ru3d_fail(-1, "conv3d: %d -> %d channels k=%d is packed in MFMA fragment order, which has no kernel for "
+                             "input dtype %d -> output dtype %d", g.Cin, g.Cout, k, dtype, y_dtype);
     return conv_generic_launch(x->ptr, w, bias, res ? res->ptr : nullptr, y->ptr, g, dtype, y_dtype, st);
 }
 

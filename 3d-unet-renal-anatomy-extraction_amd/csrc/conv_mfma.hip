@@ -1461,9 +1461,16 @@ int conv_mfma_launch(const void* x, const void* w, const float* bias, const void
     }
     {
         SlidePlan sp;
-        if ((g.ldy % 8) == 0 && (!res || (g.ldr % 8) == 0) && aligned_to(y, 16) && (!res || aligned_to(res, 16)) &&
-            slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp))
-            return conv_slide_launch(x, w, bias, res, y, g, stat_slab, st);
+        if (slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) {
+            const bool aligned = (g.ldy % 8) == 0 && (!res || (g.ldr % 8) == 0) && aligned_to(y, 16) &&
+                                 (!res || aligned_to(res, 16));
+            if (aligned) return conv_slide_launch(x, w, bias, res, y, g, stat_slab, st);
+            // the statistics slab (size, layout) was planned for the sliding kernel's grid: falling back to the
+            // producer/consumer kernel here would fill it with another geometry
+            if (stat_slab)
+                return ru3d_fail(-1, "conv_mfma: fused statistics need y (and res) 16-byte aligned with a pitch that is "
+                                     "a multiple of 8 on this shape");
+        }
     }
     MfmaConvArgs a;
     a.x = (const bf16*)x;

@@ -215,3 +215,15 @@ def test_fused_two_role_pack_equals_single_role_packs(cout, cin, k, stride, conv
         torch.cuda.synchronize()
         n = ref.numel()
         assert torch.equal(got[:n], ref) and torch.equal(single[:n], ref), role
+
+
+def test_mfma_packed_weight_is_not_handed_to_the_direct_kernel():
+    """the pack layout is chosen from (channels, k, dtype); a conv of an MFMA-packed shape with a bf16 input
+    and an fp32 output has no MFMA kernel and must fail instead of reading the pack as [tap][cin][cout_pad]."""
+    x = ops.as_input(torch.randn(1, 32, 4, 4, 4, device=DEV), torch.bfloat16)
+    w = torch.randn(32, 32, 3, 3, 3, device=DEV)
+    pw = ops.pack_weight(w, N.ROLE_CONV_FWD, torch.bfloat16, 1)
+    with pytest.raises(N.Ru3dError, match="MFMA fragment order"):
+        ops.conv_fwd(x, pw, None, 32, 3, 1, out_dtype=torch.float32)
+    y = ops.conv_fwd(x, pw, None, 32, 3, 1)                        # the supported combination still runs
+    assert y.dtype == torch.bfloat16 and torch.isfinite(y).all()
