@@ -363,6 +363,15 @@ def copy_channels(src, dst):
     check(N.lib.ru3d_copy_channels(ref(ds), ref(dd), N.dtype_code(src.dtype), stream()), "copy_channels")
 
 
+def concat_channels(a, b):
+    """cat((a, b), dim=1) as two channel-slice copies (inference paths without a tape)."""
+    n, ca, d, h, w = a.shape
+    out = N.new_act(n, ca + b.shape[1], d, h, w, a.dtype, a.device)
+    copy_channels(a, out[:, :ca])
+    copy_channels(as_grad(b, a.dtype), out[:, ca:])
+    return out
+
+
 def add(a, b):
     n, c, d, h, w = a.shape
     out = N.new_act(n, c, d, h, w, a.dtype, a.device)

@@ -94,6 +94,29 @@ def _is_plain_in(norm):
             and abs(norm.eps - ops.IN_EPS) < 1e-12)
 
 
+def _is_plain_bn(norm):
+    return (type(norm) is nn.BatchNorm3d and norm.affine and norm.track_running_stats)
+
+
+def _bn_eval_stats(norm, n, cpad):
+    """Inference-mode BatchNorm3d (reference blocks built with norm_op=nn.BatchNorm3d, network.py:38-69) is the
+    per-channel affine map gamma * (y - running_mean) / sqrt(running_var + eps) + beta.  Written for the InstanceNorm
+    apply kernel (out = lrelu((y - mean) * scale + res)): scale = gamma / sqrt(var + eps), mean = running_mean -
+    beta / scale, the same for every sample; pad lanes (channel-padded nets) get mean 0 / scale 1 so they stay 0."""
+    scale = norm.weight.detach().float() / torch.sqrt(norm.running_var.float() + norm.eps)
+    safe = torch.where(scale.abs() < 1e-20, torch.full_like(scale, 1e-20), scale)
+    mean = norm.running_mean.float() - norm.bias.detach().float() / safe
+    c = scale.numel()
+    if cpad > c:
+        mean = torch.nn.functional.pad(mean, (0, cpad - c), value=0.0)
+        safe = torch.nn.functional.pad(safe, (0, cpad - c), value=1.0)
+    return mean.repeat(n).contiguous(), safe.repeat(n).contiguous()
+
+
+def _inference_mode(module):
+    return (not module.training) and (not torch.is_grad_enabled())
+
+
 def _is_plain_lrelu(act):
     return type(act) is nn.LeakyReLU and abs(act.negative_slope - ops.LRELU_SLOPE) < 1e-12
 
@@ -227,6 +250,7 @@ class ConvTrans3D(nn.Module):
             norm_op(out_channels, **norm_kwargs),
             nonlin_op(**nonlin_kwargs))
         self._native = _is_plain_in(self.up[2]) and _is_plain_lrelu(self.up[3])
+        self._bn_eval = _is_plain_bn(self.up[2]) and _is_plain_lrelu(self.up[3])   # native in inference mode only
         self._pad = False          # set by Unet: activations carry channels zero-padded to multiples of 32
 
     def forward(self, x, skip=None, link=None):
@@ -236,8 +260,28 @@ class ConvTrans3D(nn.Module):
             return ops.UpFn.apply(x, self.up[0].weight, self.up[0].bias, skip, self._pad, link)
         if self._native:
             N.require_device(x, "ConvTrans3D input")
+        if self._bn_eval and x.is_cuda and _inference_mode(self):
+            u = self._forward_bn_eval(x)
+            return u if skip is None else ops.concat_channels(u, skip)
         y = self.up(x)
         return y if skip is None else torch.cat((y, skip), dim=1)
+
+    def _forward_bn_eval(self, x):
+        """ConvTranspose3d + far zero pad + inference BatchNorm + LeakyReLU on the native kernels (no tape)."""
+        wt, bt = self.up[0].weight, self.up[0].bias
+        x = ops.as_grad(x, x.dtype)
+        cin, cout = wt.shape[0], wt.shape[1]
+        cin_seg = ops.seg_of(cin, x.shape[1]) if self._pad else 0
+        cout_seg = cout if self._pad else 0
+        cp = ops.padded_dim(cout, cout_seg)
+        specs = [(wt, N.ROLE_CONVT_FWD, 2, cout_seg, cin_seg)]
+        if cout_seg and bt is not None:
+            specs.append((bt, N.ROLE_BIAS, 1, cout_seg, 0))
+        packs = ops.pack_weights(specs, x.dtype)
+        b = ops._f32_view(packs[-1], cp) if (cout_seg and bt is not None) else bt
+        y = ops.convt_fwd(x, packs[0], b, cp)
+        mean, scale = _bn_eval_stats(self.up[2], x.shape[0], cp)
+        return ops.in_lrelu_fwd(y, mean, scale)
 
 
 class UpConcat(nn.Module):
@@ -257,8 +301,8 @@ class UpConcat(nn.Module):
     def forward(self, x, skip, link=None):
         if not self.attention and isinstance(self.conv_trans, ConvTrans3D):
             return self.conv_trans(x, skip, link)    # up-sampled channels first, skip second
-        if (self.attention and isinstance(self.conv_trans, ConvTrans3D) and self.conv_trans._native
-                and self.att_gate._native and x.is_cuda):
+        if (self.attention and isinstance(self.conv_trans, ConvTrans3D) and self.att_gate._native and x.is_cuda
+                and (self.conv_trans._native or (self.conv_trans._bn_eval and _inference_mode(self)))):
             up = self.conv_trans(x)
             return ops.AttGateFn.apply(skip, up, self.att_gate.conv.weight, self.att_gate.conv.bias,
                                        self.conv_trans._pad)
@@ -291,6 +335,8 @@ class ResBlock(nn.Module):
                         and _is_plain_conv1(self.skip_conv) and _is_plain_in(self.norm)
                         and _is_plain_lrelu(self.nonlin)
                         and (self.dropout is None or type(self.dropout) is nn.Dropout3d))
+        self._bn_eval = (_is_plain_conv3(self.conv1) and _is_plain_conv3(self.conv2) and _is_plain_conv1(self.skip_conv)
+                         and _is_plain_bn(self.norm) and _is_plain_lrelu(self.nonlin))   # native in inference mode only
         self._forced_keep = None   # tests: inject a recorded [N, C] keep mask instead of drawing one
         self._pad = False          # set by Unet: activations carry channels zero-padded to multiples of 32
         self._in_segs = 1          # set by Unet: 2 when the input is the padded concat [up | skip]
@@ -327,6 +373,8 @@ class ResBlock(nn.Module):
                                         self._checkpoint and torch.is_grad_enabled(), in_link, out_link)
         if self._native:
             N.require_device(x, "ResBlock input")
+        if self._bn_eval and x.is_cuda and _inference_mode(self):
+            return self._forward_bn_eval(x)
         skip = self.skip_conv(x) if self.uses_skip_conv else x
         x = self.conv1(x)
         if self.dropout:
@@ -334,6 +382,38 @@ class ResBlock(nn.Module):
         x = self.nonlin(self.norm(x))
         x = self.conv2(x)
         return self.nonlin(self.norm(x) + skip)
+
+
+def _resblock_bn_eval(self, x):
+    """ResBlock with BatchNorm in inference mode on the native kernels (no tape; Dropout3d is the identity in eval):
+    conv1 -> BN -> lrelu -> conv2 -> BN -> (+ skip) -> lrelu with the ONE shared norm's running statistics."""
+    x = ops.as_grad(x, x.dtype)
+    sd = x.dtype
+    cout, cin = self.conv1.weight.shape[0], self.conv1.weight.shape[1]
+    cin_seg = ops.seg_of(cin, x.shape[1], self._in_segs) if self._pad else 0
+    cout_seg = cout if self._pad else 0
+    cp = ops.padded_dim(cout, cout_seg)
+    specs = [(self.conv1.weight, N.ROLE_CONV_FWD, self.stride, cout_seg, cin_seg),
+             (self.conv2.weight, N.ROLE_CONV_FWD, 1, cout_seg, cout_seg)]
+    if self.uses_skip_conv:
+        specs.append((self.skip_conv.weight, N.ROLE_CONV_FWD, self.stride, cout_seg, cin_seg))
+    nw = len(specs)
+    biases = [self.conv1.bias, self.conv2.bias, self.skip_conv.bias if self.uses_skip_conv else None]
+    if cout_seg:
+        specs += [(b, N.ROLE_BIAS, 1, cout_seg, 0) for b in biases if b is not None]
+    packs = ops.pack_weights(specs, sd)
+    if cout_seg:
+        it = iter(packs[nw:])
+        biases = [(ops._f32_view(next(it), cp) if b is not None else None) for b in biases]
+    mean, scale = _bn_eval_stats(self.norm, x.shape[0], cp)
+    y1 = ops.conv_fwd(x, packs[0], biases[0], cp, 3, self.stride)
+    a1 = ops.in_lrelu_fwd(y1, mean, scale)
+    y2 = ops.conv_fwd(a1, packs[1], biases[1], cp, 3, 1)
+    skip = ops.conv_fwd(x, packs[2], biases[2], cp, 1, self.stride) if self.uses_skip_conv else x
+    return ops.in_lrelu_fwd(y2, mean, scale, res=skip)
+
+
+ResBlock._forward_bn_eval = _resblock_bn_eval
 
 
 class ResBlockStack(nn.Module):
@@ -396,25 +476,37 @@ class Unet(nn.Module):
         self._native_io = _is_plain_conv3(self.conv) and _is_plain_conv1(self.fc)
         self._pad = False
         self._linked = False
+        self._bn_blocks = None
+        self._in_chain = False
+        self._pad_bn = False
         self._configure_native()
 
-    def _native_chain(self):
-        """The native blocks between stem and head, or None when any block on the path is a torch module."""
+    def _native_chain(self, bn_ok=False):
+        """The native blocks between stem and head, or None when any block on the path is a torch module.
+        bn_ok: also accept a chain of BatchNorm blocks (native in inference mode only)."""
         blocks = []
         for blk in list(self.pool_blocks) + list(self.encode_blocks) + list(self.decode_blocks):
             if isinstance(blk, ResBlockStack):
                 blocks += list(blk.res_blocks)
             else:
                 blocks.append(blk)
+        kinds = set()
         for blk in blocks:
-            if not (isinstance(blk, ResBlock) and blk._native):
+            if not (isinstance(blk, ResBlock) and (blk._native or blk._bn_eval)):
                 return None
+            kinds.add("in" if blk._native else "bn")
         for up in self.up_blocks:
-            if not (isinstance(up, UpConcat) and isinstance(up.conv_trans, ConvTrans3D) and up.conv_trans._native
+            if not (isinstance(up, UpConcat) and isinstance(up.conv_trans, ConvTrans3D)
+                    and (up.conv_trans._native or up.conv_trans._bn_eval)
                     and (not up.attention or up.att_gate._native)):
                 return None
+            kinds.add("in" if up.conv_trans._native else "bn")
             blocks.append(up.conv_trans)
-        return blocks if self._native_io else None
+        if len(kinds) != 1 or not self._native_io:
+            return None
+        if "bn" in kinds and not bn_ok:
+            return None
+        return blocks
 
     def _configure_native(self):
         """Channel padding: with a 16-bit storage dtype, widths that are not multiples of 32 (the reference's default
@@ -423,6 +515,15 @@ class Unet(nn.Module):
         InstanceNorm, LeakyReLU and their gradients; weights are packed with zero rows/columns and weight gradients
         are cut back to the parameters' shapes).  Forward hooks on inner blocks see the padded channel counts."""
         chain = self._native_chain()
+        bn_chain = self._native_chain(bn_ok=True) if chain is None else None
+        self._bn_blocks = bn_chain
+        self._in_chain = chain is not None
+        self._pad_bn = False
+        if bn_chain is not None:
+            wb = [c for blk in bn_chain for c in (blk.in_channels, blk.out_channels)]
+            self._pad_bn = (self.compute_dtype != torch.float32 and any(c % 32 for c in wb)
+                            and all(ops.cpad(c) * 2 <= 3 * c for c in wb)
+                            and os.environ.get("RU3D_PAD_CHANNELS", "1") != "0")
         widths = []
         if chain is not None:
             for blk in chain:
@@ -445,10 +546,17 @@ class Unet(nn.Module):
             if isinstance(first, ResBlock):
                 first._in_segs = 2
 
+    def _storage_dtype(self):
+        """16-bit storage only where the blocks behind the stem consume it: an all-native InstanceNorm chain, or a
+        BatchNorm chain in inference mode; torch-module blocks (BatchNorm training, custom blocks) get fp32."""
+        if self._in_chain or (self._bn_blocks is not None and _inference_mode(self)):
+            return self.compute_dtype
+        return torch.float32
+
     def _stem(self, x):
         if self._native_io and x.is_cuda:
-            return ops.ConvFn.apply(x, self.conv.weight, self.conv.bias, 1, self.compute_dtype, self.compute_dtype,
-                                    False, self._pad)
+            sd = self._storage_dtype()
+            return ops.ConvFn.apply(x, self.conv.weight, self.conv.bias, 1, sd, sd, False, self._pad)
         if self._native_io:
             N.require_device(x, "Unet input")
         return self.conv(x)
@@ -458,7 +566,16 @@ class Unet(nn.Module):
             return ops.ConvFn.apply(x, self.fc.weight, self.fc.bias, 1, x.dtype, torch.float32, self._pad, False)
         return self.fc(x)
 
+    def _set_bn_pad(self, pad):
+        """BatchNorm nets are native in inference mode only, so their channel padding is decided per forward."""
+        if pad != self._pad:
+            self._pad = pad
+            for blk in self._bn_blocks:
+                blk._pad = pad
+
     def forward(self, x):
+        if self._bn_blocks is not None:
+            self._set_bn_pad(self._pad_bn and x.is_cuda and _inference_mode(self))
         x = self._stem(x)
         skips, links = [], []
         linked = self._linked and x.is_cuda
@@ -539,7 +656,9 @@ class ResAttrUnet3D2(_UnetWrapper):
 
 
 class ResAttrBNUnet3D(_UnetWrapper):
-    """BatchNorm + attention variant (torch ops: BatchNorm is outside the native hot path)."""
+    """BatchNorm + attention variant.  Training runs its blocks as torch modules (batch statistics, running averages);
+    inference (eval + no_grad - how the reference's scripts use this net, as the coarse model of nb_post_iia.py:20)
+    runs on the native kernels: BatchNorm with running statistics is a per-channel affine map."""
 
     def __init__(self, num_pool=4, num_features=30, in_channels=1, out_channels=1):
         super().__init__()

@@ -40,6 +40,10 @@ def main():
         for k, v in model.state_dict().items():
             if "running_" in k or "num_batches" in k:
                 out["%s/after/%s" % (tag, k)] = v.detach().numpy().copy()
+        if train:      # inference with the running statistics the training forward left behind
+            model.eval()
+            with torch.no_grad():
+                out[tag + "/logits_eval"] = model(x).numpy()
         print(tag, float(loss), logits.shape)
     np.savez_compressed(os.path.join(G.OUT, "g8_variants.npz"), **out)
     print("wrote g8_variants.npz")

@@ -110,3 +110,52 @@ def test_attention_gate_16_bit_and_padded(feat, dtype):
         if p.grad is not None:
             assert p.grad.shape == p.shape and torch.isfinite(p.grad).all(), k
     assert model.net.up_blocks[0].att_gate.conv.weight.grad.abs().max().item() > 0
+
+
+def test_res_attr_bn_unet_inference_runs_native_and_matches_reference(golden_dir):
+    """Inference mode (eval + no_grad) of the BatchNorm variant runs on the native kernels (BatchNorm with running
+    statistics = per-channel affine through the norm-apply kernel, attention gate native): logits against the
+    reference's eval-mode forward with the running statistics its training forward left behind."""
+    z, model, x, y = _load(golden_dir, "attrbn", network.ResAttrBNUnet3D, False)
+    sd = model.state_dict()
+    for k in list(sd):
+        key = "attrbn/after/" + k
+        if key in z.files:
+            sd[k] = torch.from_numpy(z[key]).to(sd[k].device)
+    model.load_state_dict(sd)
+    assert model.net._bn_blocks is not None and model.net._native_chain() is None
+    calls = []
+    orig = network.ResBlock._forward_bn_eval
+    network.ResBlock._forward_bn_eval = lambda self, t: (calls.append(1), orig(self, t))[1]
+    try:
+        with torch.no_grad():
+            logits = model(x)
+    finally:
+        network.ResBlock._forward_bn_eval = orig
+    assert len(calls) == 8                                  # 4 encode + 2 pool + 2 decode blocks, all native
+    ref = torch.from_numpy(z["attrbn/logits_eval"])
+    assert (logits.cpu() - ref).abs().max().item() <= 2e-4
+    assert (logits.argmax(1).cpu() != ref.argmax(1)).float().mean().item() < 1e-4
+    # with the tape on, the same call goes through the torch modules and still matches
+    logits_t = model(x)
+    assert len(calls) == 8 and (logits_t.detach().cpu() - ref).abs().max().item() <= 2e-4
+
+
+@pytest.mark.parametrize("feat,dtype", [(32, torch.bfloat16), (30, torch.bfloat16)])
+def test_bn_inference_16_bit_and_padded(feat, dtype):
+    torch.manual_seed(4)
+    model = network.ResAttrBNUnet3D(2, feat, 1, 2).to(DEV)
+    x = torch.randn(2, 1, 32, 32, 32, device=DEV)
+    model.train()
+    with torch.no_grad():
+        model(x)                                            # one training forward: non-trivial running statistics
+    model.eval()
+    with torch.no_grad():
+        ref = model(x)
+        network.set_compute_dtype(model, dtype)
+        got = model(x)
+    assert model.net._pad == (feat == 30)
+    assert (got - ref).abs().max().item() <= 0.15
+    model.train()
+    out = model(x)                                          # back to the torch modules: un-padded again
+    assert not model.net._pad and torch.isfinite(out).all()
