@@ -244,7 +244,13 @@ def main():
         broadcast_parameters(model)
         transport = os.environ.get("RU3D_COMM", "torch" if one_device else "rccl")
         gd = torch.bfloat16 if (args.grad_transport == "bf16" and transport == "rccl") else torch.float32
-        sync = GradSync(model, transport=transport, grad_dtype=gd)
+        try:
+            sync = GradSync(model, transport=transport, grad_dtype=gd)
+        except Exception as e:      # e.g. no RCCL library on the box: every rank fails alike - exchange over gloo instead
+            print("bench.py rank %d: RCCL exchange unavailable (%r); falling back to torch.distributed" % (rank, e),
+                  file=sys.stderr, flush=True)
+            transport = "torch"
+            sync = GradSync(model, transport="torch")
     if args.optimizer == "fused":
         import optim
         opt = optim.Adam(model.parameters(), lr=1e-4)      # same update rule, one launch for the whole model
