@@ -98,6 +98,11 @@ bool slide_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* o
 int conv_slide_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
                       float* stat_slab, hipStream_t st);
 
+// conv_slide64.hip (3x3x3 stride-1, 64 -> 64 / 128 channels: the same design on v_mfma_f32_16x16x32, a wave = 16 couts)
+bool slide64_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* out);
+int conv_slide64_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
+                        float* stat_slab, hipStream_t st);
+
 // wgrad_slide.hip (3x3x3 stride-1 weight gradient on the large levels: D-sliding plane ring)
 struct WgradSlidePlan {
     int dsplit, DL, tiles_h, tiles_w, units, G, pairs;

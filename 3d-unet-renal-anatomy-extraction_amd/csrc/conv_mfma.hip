@@ -651,6 +651,7 @@ size_t conv_mfma_ws_bytes(const ConvGeom& g) {
     if (!(g.k == 3 && g.stride == 1 && !g.transposed && (g.Cin % 32) == 0 && (g.Cout % 32) == 0)) return 0;
     SlidePlan sp;
     if (slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) return 0;
+    if (slide64_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) return 0;
     const S1Plan p = s1_plan(g.N, g.Do, g.Ho, g.Wo, g.Cout);
     const int ks = s1_ksplit(p, g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout);
     return ks > 1 ? (size_t)ks * g.N * g.Do * g.Ho * g.Wo * g.Cout * sizeof(float) : 0;
@@ -697,6 +698,7 @@ bool mfma_conv_can_fuse_stats(const ConvGeom& g) {
     if (!(g.k == 3 && g.stride == 1 && !g.transposed && (g.Cin % 32) == 0 && (g.Cout % 32) == 0)) return false;
     SlidePlan sp;
     if (slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) return true;
+    if (slide64_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) return true;
     return s1_plan(g.N, g.Do, g.Ho, g.Wo, g.Cout).pc;
 }
 
@@ -706,6 +708,12 @@ static void stats_slab_geom(const ConvGeom& g, int* gx, int* gy, int* cb) {
         *gx = sp.grid;
         *gy = sp.ny;
         *cb = 32;
+        return;
+    }
+    if (slide64_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) {
+        *gx = sp.grid;
+        *gy = sp.ny;
+        *cb = 64;
         return;
     }
     const S1Plan p = s1_plan(g.N, g.Do, g.Ho, g.Wo, g.Cout);
@@ -1467,6 +1475,14 @@ int conv_mfma_launch(const void* x, const void* w, const float* bias, const void
             if (aligned) return conv_slide_launch(x, w, bias, res, y, g, stat_slab, st);
             // the statistics slab (size, layout) was planned for the sliding kernel's grid: falling back to the
             // producer/consumer kernel here would fill it with another geometry
+            if (stat_slab)
+                return ru3d_fail(-1, "conv_mfma: fused statistics need y (and res) 16-byte aligned with a pitch that is "
+                                     "a multiple of 8 on this shape");
+        }
+        if (slide64_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) {
+            const bool aligned = (g.ldy % 8) == 0 && (!res || (g.ldr % 8) == 0) && aligned_to(y, 16) &&
+                                 (!res || aligned_to(res, 16));
+            if (aligned) return conv_slide64_launch(x, w, bias, res, y, g, stat_slab, st);
             if (stat_slab)
                 return ru3d_fail(-1, "conv_mfma: fused statistics need y (and res) 16-byte aligned with a pitch that is "
                                      "a multiple of 8 on this shape");

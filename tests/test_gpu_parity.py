@@ -417,13 +417,16 @@ def test_conv_with_channel_pitch_and_odd_extents(dtype):
 @pytest.mark.parametrize("shape", [(2, 32, 32, 5, 9, 37), (1, 64, 32, 4, 6, 20), (1, 64, 64, 3, 10, 12),
                                    (1, 128, 64, 5, 5, 7), (1, 32, 96, 2, 3, 33), (1, 32, 32, 8, 8, 8),
                                    (2, 32, 32, 64, 64, 64), (1, 32, 32, 24, 64, 96), (5, 32, 32, 4, 128, 128),
-                                   (2, 32, 64, 32, 64, 64)])
+                                   (2, 32, 64, 32, 64, 64), (2, 64, 64, 64, 64, 64), (1, 64, 64, 8, 8, 32),
+                                   (3, 64, 128, 12, 16, 64)])
 def test_mfma_conv_s1_bf16(shape):
     """The bf16 MFMA implicit-GEMM kernel (3x3x3, stride 1) on ragged extents, with bias + residual, as a
     forward conv and as the tap-reversed input gradient, and the wgrad of the same shapes.  Reference:
     torch CPU conv in fp32 on the bf16-rounded operands; tolerance = bf16 output rounding (2^-8 of max).
     The last four shapes take the D-sliding kernel (conv_slide.hip): 256 / 144 / 320 work units (the third with
-    more units than workgroups and five samples), and 32 -> 64 channels as two output slices."""
+    more units than workgroups and five samples), and 32 -> 64 channels as two output slices; the last three the
+    64-channel sliding kernel (conv_slide64.hip, v_mfma_f32_16x16x32): the level-1 shape of config 2, a single short
+    column, and 64 -> 128 channels as two slices with three samples."""
     n, cin, cout, d, h, w = shape
     g = torch.Generator().manual_seed(sum(shape))
     xw = torch.randn(n, cin + 32, d, h, w, generator=g)
@@ -525,7 +528,8 @@ def test_mfma_convtranspose_bf16(cin, cout, dims):
 
 @pytest.mark.parametrize("shape", [(2, 32, 32, 40, 36, 64), (1, 64, 64, 33, 40, 48), (3, 32, 64, 24, 24, 24),
                                    (1, 32, 32, 6, 6, 8), (2, 32, 32, 64, 64, 64), (5, 32, 32, 4, 128, 128),
-                                   (3, 32, 32, 16, 64, 64), (2, 32, 64, 32, 64, 64)])
+                                   (3, 32, 32, 16, 64, 64), (2, 32, 64, 32, 64, 64), (2, 64, 64, 64, 64, 64),
+                                   (3, 64, 128, 12, 16, 64)])
 def test_conv_fwd_in_fused_statistics(shape):
     """ru3d_conv3d_fwd_in: conv + InstanceNorm statistics.  On the persistent producer/consumer MFMA kernel the
     sums come from the conv epilogue; they must agree with a separate statistics pass over the stored output

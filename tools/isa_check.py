@@ -8,6 +8,9 @@ VGPR / AGPR / spill / scratch figures from the code-object metadata, and FAILS (
   * a kernel that issues inline-asm MFMAs (the D-sliding conv / weight-gradient kernels) has a `scratch_` instruction
     between its first and last `v_mfma` - the compiler's hazard recogniser cannot see those MFMAs' operands, so a
     spill restore next to them is the hazard the hand-placed `s_nop`s do not cover (conv_slide.hip step()), or
+  * in the 64-channel sliding kernel (all weights in AGPRs, the allocator parks loop-invariant VGPRs in the remaining
+    AGPRs and a few pointers in scratch) a `v_accvgpr_write` between the MFMAs targets an AGPR that an MFMA of the
+    kernel reads, or a VALU instruction writes a source register of an MFMA one or two instructions ahead of it, or
   * any kernel on the hot path spills more VGPRs than the committed allowance below (a compiler bump that pushes a
     512-register kernel over the edge shows up here, not as a silent slowdown).
 """
@@ -21,13 +24,66 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "3d-unet-renal-anatomy-extraction_amd", "csrc")
-SRCS = ["conv_slide.hip", "wgrad_slide.hip", "wgrad_s2.hip", "conv_mfma.hip", "small_convs.hip", "conv_generic.hip",
+SRCS = ["conv_slide.hip", "conv_slide64.hip", "wgrad_slide.hip", "wgrad_s2.hip", "conv_mfma.hip", "small_convs.hip", "conv_generic.hip",
         "norm.hip", "loss.hip", "predict.hip", "comm.hip"]
-TWICE = {"conv_slide.hip", "wgrad_slide.hip", "wgrad_s2.hip", "conv_mfma.hip", "small_convs.hip", "conv_generic.hip",
+TWICE = {"conv_slide.hip", "conv_slide64.hip", "wgrad_slide.hip", "wgrad_s2.hip", "conv_mfma.hip", "small_convs.hip", "conv_generic.hip",
          "norm.hip"}
 # spilled VGPRs tolerated per kernel-name pattern (everything else: 0)
-ALLOW = [(r"conv3_s1_slide32_kernel", 64), (r"conv3_s1_pc_kernel", 16), (r"wgrad3_s1_slide_kernel", 16)]
+ALLOW = [(r"conv3_s1_slide32_kernel", 64), (r"conv3_s1_slide64_kernel", 64), (r"conv3_s1_pc_kernel", 16), (r"wgrad3_s1_slide_kernel", 16)]
 NO_SCRATCH_IN_MFMA_SPAN = [r"conv3_s1_slide32_kernel", r"wgrad3_s1_slide_kernel"]
+NO_COPY_INTO_MFMA_OPERANDS = [r"conv3_s1_slide64_kernel"]
+
+
+def regs_of(tok):
+    """'v[4:7]' / 'a12' -> set of ('v'|'a', index)"""
+    m = re.fullmatch(r"([va])\[(\d+):(\d+)\]", tok)
+    if m:
+        return {(m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1)}
+    m = re.fullmatch(r"([va])(\d+)", tok)
+    return {(m.group(1), int(m.group(2)))} if m else set()
+
+
+def copies_into_mfma_operands(lines, mf):
+    """Two hazards the compiler cannot see through inline asm: (1) a v_accvgpr_write between the MFMAs into an AGPR
+    that some MFMA of the kernel reads (the weights stay put, so any such write is a copy-back); (2) a VALU write to a
+    VGPR/AGPR that one of the next two instructions, an MFMA, takes as a source."""
+    tok_re = r"[va]\[\d+:\d+\]|\b[va]\d+\b"
+    agpr_ops = set()
+    for i in mf:
+        for tok in re.findall(tok_re, lines[i]):
+            agpr_ops |= {r for r in regs_of(tok) if r[0] == "a"}
+    bad = 0
+    code = [l for l in lines[mf[0]:mf[-1] + 1] if l.strip() and not l.strip().startswith((";", "."))]
+    for n, l in enumerate(code):
+        m = re.match(r"\s*v_accvgpr_write_b32\s+(a\d+)", l)
+        if m and regs_of(m.group(1)) & agpr_ops:
+            bad += 1
+        if "v_mfma" in l:
+            srcs = set()
+            for tok in re.findall(tok_re, l)[1:]:
+                srcs |= regs_of(tok)
+            for prev in code[max(0, n - 2):n]:
+                pm = re.match(r"\s*(v_\w+)\s+(" + tok_re + ")", prev)
+                if pm and not pm.group(1).startswith("v_mfma") and regs_of(pm.group(2)) & srcs:
+                    bad += 1
+        # (3) an MFMA result read by a non-MFMA instruction fewer than 11 wait states later (MFMA = 4, s_nop k = k + 1)
+        if "v_mfma" in l:
+            dst = regs_of(re.findall(tok_re, l)[0])
+            wait = 0
+            for nxt in code[n + 1:n + 12]:
+                if wait >= 11:
+                    break
+                if "v_mfma" not in nxt:
+                    toks = re.findall(tok_re, nxt)
+                    used = set()
+                    for tok in toks:
+                        used |= regs_of(tok)
+                    if used & dst and not re.match(r"\s*s_", nxt):
+                        bad += 1
+                        break
+                nm = re.match(r"\s*s_nop\s+(\d+)", nxt)
+                wait += 4 if "v_mfma" in nxt else (int(nm.group(1)) + 1 if nm else 1)
+    return bad
 
 
 def compile_asm(src, f16, tmp):
@@ -63,6 +119,7 @@ def parse(path):
         if mf:
             inside = sum(1 for l in lines[mf[0]:mf[-1] + 1] if re.search(r"\bscratch_(load|store)", l))
         kernels[name] = {"mfma": len(mf), "scratch_in_mfma_span": inside,
+                         "copies_into_operands": copies_into_mfma_operands(lines, mf) if mf else 0,
                          "scratch_total": sum(1 for l in lines if re.search(r"\bscratch_(load|store)", l))}
     for m in re.finditer(r"- \.agpr_count:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?"
                          r"\.sgpr_count:\s+(\d+).*?\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", text, re.S):
@@ -98,6 +155,9 @@ def main():
                 if any(re.search(p, nice) for p in NO_SCRATCH_IN_MFMA_SPAN) and k["scratch_in_mfma_span"]:
                     failures.append("%s: %s has %d scratch instruction(s) between its first and last v_mfma"
                                     % (src, nice, k["scratch_in_mfma_span"]))
+                if any(re.search(p, nice) for p in NO_COPY_INTO_MFMA_OPERANDS) and k["copies_into_operands"]:
+                    failures.append("%s: %s copies into an MFMA operand register next to / between its MFMAs "
+                                    "(%d times)" % (src, nice, k["copies_into_operands"]))
     lines = ["%-24s %-62s %5s %5s %5s %6s %8s %6s %s" % ("source", "kernel", "vgpr", "agpr", "sgpr", "spill", "scratchB",
                                                           "mfma", "scratch-in-mfma-span")]
     for r in rows:
