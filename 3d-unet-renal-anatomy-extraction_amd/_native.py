@@ -72,6 +72,7 @@ SIGNATURES = {
     "ru3d_in_lrelu_bwd": (_i, [_P, _P, _P, _vp, _vp, _P, _P, _vp, _sz, _f, _i, _vp, _i, _vp]),
     "ru3d_channel_sum": (_i, [_P, _vp, _vp, _sz, _i, _vp]),
     "ru3d_dropout3d_scale": (_i, [_vp, _i, _f, _u64, _u64, _vp]),
+    "ru3d_dropout3d_scale_dev": (_i, [_vp, _i, _f, _u64, _u64, _vp, _vp]),
     "ru3d_pointwise": (_i, [_i, _P, _P, _P, _P, _P, _f, _i, _vp]),
     "ru3d_copy_channels": (_i, [_P, _P, _i, _vp]),
     "ru3d_add": (_i, [_P, _P, _P, _i, _vp]),
@@ -87,6 +88,7 @@ SIGNATURES = {
     "ru3d_predict_accumulate": (_i, [_P, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ru3d_predict_merge": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ru3d_adam_multi": (_i, [_vp, _vp, _i, _i, _f, _f, _f, _f, _f, _f, _f, _vp]),
+    "ru3d_adam_multi_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ru3d_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp]),
     "ru3d_augment_workspace_bytes": (_sz, [_i, _i, _i]),
     "ru3d_augment_label_presence": (_i, [_vp, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int32),

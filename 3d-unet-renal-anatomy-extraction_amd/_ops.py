@@ -419,6 +419,9 @@ def _dist_rank():
 
 _drop_lock = threading.Lock()
 _drop_counter = [0]
+# graph.GraphedTrainStep sets this while it captures a step: an int64 device scalar the captured dropout launches add
+# to their (frozen) counter offsets, so that replay k draws the masks of eager step k
+DROP_OFFSET_BASE = [None]
 
 
 def dropout_scale(n, c, p, device):
@@ -430,8 +433,13 @@ def dropout_scale(n, c, p, device):
     N.note_device(out.device)
     # one process per GPU: every rank draws its own masks even when all ranks were seeded alike
     seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * _dist_rank()) & 0xFFFFFFFFFFFFFFFF
-    check(N.lib.ru3d_dropout3d_scale(ptr(out), n * c, float(p), ctypes.c_uint64(seed), ctypes.c_uint64(offset),
-                                     stream()), "dropout3d_scale")
+    base = DROP_OFFSET_BASE[0]
+    if base is not None:
+        check(N.lib.ru3d_dropout3d_scale_dev(ptr(out), n * c, float(p), ctypes.c_uint64(seed), ctypes.c_uint64(offset),
+                                             ptr(base), stream()), "dropout3d_scale_dev")
+    else:
+        check(N.lib.ru3d_dropout3d_scale(ptr(out), n * c, float(p), ctypes.c_uint64(seed), ctypes.c_uint64(offset),
+                                         stream()), "dropout3d_scale")
     return out
 
 

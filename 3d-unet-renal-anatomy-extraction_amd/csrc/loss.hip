@@ -417,10 +417,9 @@ extern "C" int ru3d_adam_step(float* param, const float* grad, float* exp_avg, f
 }
 
 // multi-tensor form: one launch for the whole model (device-side tensor table + block map)
-__global__ __launch_bounds__(256) void adam_multi_kernel(const ru3d_adam_tensor* __restrict__ tensors,
-                                                         const int32_t* __restrict__ block_map, int chunk_elems,
-                                                         float lr, float b1, float b2, float eps, float bc1,
-                                                         float bc2_sqrt, float gscale) {
+__device__ __forceinline__ void adam_multi_body(const ru3d_adam_tensor* __restrict__ tensors,
+                                                const int32_t* __restrict__ block_map, int chunk_elems, float lr,
+                                                float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
     const ru3d_adam_tensor t = tensors[block_map[2 * blockIdx.x]];
     if (!t.grad) return;
     const int64_t begin = (int64_t)block_map[2 * blockIdx.x + 1] * chunk_elems;
@@ -459,6 +458,21 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const ru3d_adam_tensor*
         }
 }
 
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const ru3d_adam_tensor* __restrict__ tensors,
+                                                         const int32_t* __restrict__ block_map, int chunk_elems,
+                                                         float lr, float b1, float b2, float eps, float bc1,
+                                                         float bc2_sqrt, float gscale) {
+    adam_multi_body(tensors, block_map, chunk_elems, lr, b1, b2, eps, bc1, bc2_sqrt, gscale);
+}
+
+// the per-step scalars from device memory (a captured launch: see ru3d.h)
+__global__ __launch_bounds__(256) void adam_multi_dev_kernel(const ru3d_adam_tensor* __restrict__ tensors,
+                                                             const int32_t* __restrict__ block_map, int chunk_elems,
+                                                             const float* __restrict__ hyper) {
+    adam_multi_body(tensors, block_map, chunk_elems, hyper[0], hyper[1], hyper[2], hyper[3], hyper[4], hyper[7], hyper[6]);
+}
+
 extern "C" int ru3d_adam_multi(const ru3d_adam_tensor* tensors, const int32_t* block_map, int nblocks, int chunk_elems,
                                float lr, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
                                float grad_scale, void* stream) {
@@ -468,6 +482,16 @@ extern "C" int ru3d_adam_multi(const ru3d_adam_tensor* tensors, const int32_t* b
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, as_stream(stream), tensors, block_map,
                        chunk_elems, lr, beta1, beta2, eps, bias_corr1, sqrtf(bias_corr2), grad_scale);
     return ru3d_check_launch("adam_multi");
+}
+
+extern "C" int ru3d_adam_multi_dev(const ru3d_adam_tensor* tensors, const int32_t* block_map, int nblocks,
+                                   int chunk_elems, const float* hyper, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(tensors && block_map && hyper && nblocks > 0 && chunk_elems >= 1024 && (chunk_elems % 1024) == 0,
+                 "adam_multi_dev: bad argument (chunk_elems must be a positive multiple of 1024)");
+    hipLaunchKernelGGL(adam_multi_dev_kernel, dim3((unsigned)nblocks), dim3(256), 0, as_stream(stream), tensors,
+                       block_map, chunk_elems, hyper);
+    return ru3d_check_launch("adam_multi_dev");
 }
 
 // --------------------------------------------------------------------------- loss scaling (fp16 storage)

@@ -725,9 +725,10 @@ extern "C" int ru3d_cast_f32(const ru3d_tensor* src, const ru3d_tensor* dst, int
 // --------------------------------------------------------------------------- dropout mask
 // Counter-based generator (splitmix64 of (seed, offset + i)); one draw per (n, c) volume.
 __global__ void dropout_scale_kernel(float* __restrict__ scale, int count, float p, uint64_t seed,
-                                     uint64_t offset) {
+                                     uint64_t offset, const uint64_t* __restrict__ offset_base) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
+    if (offset_base) offset += *offset_base;
     uint64_t z = seed * 0x9E3779B97F4A7C15ull + (offset + (uint64_t)i + 1) * 0xBF58476D1CE4E5B9ull;
     z ^= z >> 30;
     z *= 0xBF58476D1CE4E5B9ull;
@@ -744,8 +745,17 @@ extern "C" int ru3d_dropout3d_scale(float* scale, int count, float p, uint64_t s
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(scale && count > 0 && p >= 0.f && p < 1.f, "dropout3d_scale: bad argument");
     hipLaunchKernelGGL(dropout_scale_kernel, dim3((count + 255) / 256), dim3(256), 0, as_stream(stream), scale, count,
-                       p, seed, offset);
+                       p, seed, offset, (const uint64_t*)nullptr);
     return ru3d_check_launch("dropout3d_scale");
+}
+
+extern "C" int ru3d_dropout3d_scale_dev(float* scale, int count, float p, uint64_t seed, uint64_t offset,
+                                        const uint64_t* offset_base, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(scale && offset_base && count > 0 && p >= 0.f && p < 1.f, "dropout3d_scale_dev: bad argument");
+    hipLaunchKernelGGL(dropout_scale_kernel, dim3((count + 255) / 256), dim3(256), 0, as_stream(stream), scale, count,
+                       p, seed, offset, offset_base);
+    return ru3d_check_launch("dropout3d_scale_dev");
 }
 #endif
 

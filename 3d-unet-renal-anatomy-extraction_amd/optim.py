@@ -30,10 +30,12 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
         self._plans = {}
+        self._captured = None       # graph.GraphedTrainStep: {"hyper": device float32[groups, 8], "steps": [..]}
 
-    def _plan(self, gi, group):
-        """Static part of the launch: block map + pinned host table (built once per param group)."""
-        plan = self._plans.get(gi)
+    def _plan(self, gi, group, captured=False):
+        """Static part of the launch: block map + pinned host table (built once per param group; a captured step keeps
+        its own table - its memcpy node re-reads the pinned block at every replay)."""
+        plan = self._plans.get((gi, captured))
         params = [p for p in group["params"]]
         if plan is not None and plan["n"] == len(params):
             return plan
@@ -49,7 +51,7 @@ class Adam(torch.optim.Optimizer):
         host = torch.empty(len(params) * ctypes.sizeof(_AdamTensor), dtype=torch.uint8).pin_memory()
         table = torch.empty(host.numel(), dtype=torch.uint8, device=dev)
         plan = {"n": len(params), "block_map": bm, "nblocks": len(blocks) // 2, "host": host, "table": table}
-        self._plans[gi] = plan
+        self._plans[(gi, captured)] = plan
         return plan
 
     @torch.no_grad()
@@ -59,14 +61,17 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        capturing = self._captured is not None and torch.cuda.is_current_stream_capturing()
+        if self._captured is not None and not capturing:
+            self.sync_captured_steps()           # an eager step between replays continues their step count
         for gi, group in enumerate(self.param_groups):
             params = group["params"]
             if not params:
                 continue
-            plan = self._plan(gi, group)
+            plan = self._plan(gi, group, capturing)
             N.note_device(params[0].device)
             b1, b2 = group["betas"]
-            if plan.get("copied") is not None:
+            if plan.get("copied") is not None and not capturing:
                 plan["copied"].synchronize()     # previous step's async H2D of the table has left the host buffer
             arr = (_AdamTensor * len(params)).from_buffer(plan["host"].numpy())
             step_no = None
@@ -81,6 +86,9 @@ class Adam(torch.optim.Optimizer):
                     g = g.float().contiguous()
                     p.grad = g
                 if len(st) == 0:
+                    if capturing:
+                        raise N.Ru3dError("optim.Adam: take one eager step before capturing (the moment buffers are "
+                                          "created and zeroed by the first step)")
                     st["step"] = torch.tensor(0.0)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
@@ -94,9 +102,20 @@ class Adam(torch.optim.Optimizer):
             if not any_grad:
                 continue
             plan["table"].copy_(plan["host"], non_blocking=True)
+            if capturing:
+                # the captured launch reads lr / bias corrections / grad_scale from the device block that
+                # hyper_for_replay() refreshes in front of every replay; the table copy is part of the graph (the
+                # gradients live at fixed addresses of the graph's memory pool)
+                plan["copied"] = None
+                self._captured["steps"][gi] = step_no - 1.0     # the first replay IS this step
+                check(N.lib.ru3d_adam_multi_dev(ptr(plan["table"]), ptr(plan["block_map"]), plan["nblocks"], _CHUNK,
+                                                ptr(self._captured["hyper"][gi]), stream()), "adam_multi_dev")
+                continue
             ev = torch.cuda.Event()
             ev.record()
             plan["copied"] = ev
+            if self._captured is not None and gi in self._captured["steps"]:
+                self._captured["steps"][gi] = step_no
             bc1 = 1.0 - b1 ** step_no
             bc2 = 1.0 - b2 ** step_no
             check(N.lib.ru3d_adam_multi(ptr(plan["table"]), ptr(plan["block_map"]), plan["nblocks"], _CHUNK,
@@ -105,6 +124,48 @@ class Adam(torch.optim.Optimizer):
         import _ops
         _ops.WEIGHTS_EPOCH[0] += 1      # packed copies of the weights are stale now
         return loss
+
+
+    # ---- a training step captured in a hipGraph (graph.GraphedTrainStep)
+    def begin_capture(self, hyper):
+        """hyper: device float32 [len(param_groups), 8]; the captured update kernels read their scalars from it."""
+        if hyper.shape != (len(self.param_groups), 8) or hyper.dtype != torch.float32:
+            raise ValueError("begin_capture: hyper must be float32 [groups, 8]")
+        self._captured = {"hyper": hyper, "steps": {}}
+        for gi, group in enumerate(self.param_groups):       # device-side plan pieces cannot be made while capturing
+            if group["params"]:
+                self._plan(gi, group, True)
+
+    def replay_scalars(self, out, grad_scale=1.0):
+        """Advance the step counts of the captured groups by one and write this step's scalars into `out` (CPU float32
+        [groups, 8]: lr, beta1, beta2, eps, bias_corr1, bias_corr2, grad_scale, sqrt(bias_corr2)) - the caller uploads them."""
+        cap = self._captured
+        cap["dirty"] = True
+        for gi, step_no in cap["steps"].items():
+            step_no += 1.0
+            cap["steps"][gi] = step_no
+            group = self.param_groups[gi]
+            b1, b2 = group["betas"]
+            row = out[gi]
+            row[0] = group["lr"]; row[1] = b1; row[2] = b2; row[3] = group["eps"]
+            row[4] = 1.0 - b1 ** step_no; row[5] = 1.0 - b2 ** step_no; row[6] = grad_scale
+            row[7] = float(row[5]) ** 0.5     # sqrt of the float32 bias_corr2, as ru3d_adam_multi takes it on the host
+
+    def sync_captured_steps(self):
+        """Write the step counts reached by graph replays back into state[p]['step'] (state_dict fidelity)."""
+        cap = self._captured
+        if cap is None or not cap.get("dirty"):
+            return
+        cap["dirty"] = False
+        for gi, step_no in cap["steps"].items():
+            for p in self.param_groups[gi]["params"]:
+                st = self.state.get(p)
+                if st:
+                    st["step"] = torch.tensor(float(step_no))
+
+    def state_dict(self):
+        self.sync_captured_steps()
+        return super().state_dict()
 
 
 class _GradTable:

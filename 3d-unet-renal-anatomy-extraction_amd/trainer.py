@@ -82,7 +82,8 @@ class Trainer():
                  dataloader_kwargs={'num_workers': 2, 'pin_memory': True},
                  valid_split=0.2, num_samples=None, metrics=None, scheduler=None,
                  train_transform=None, valid_transform=None,
-                 criterion=None, tr_transform=None, vd_transform=None, sync_every=1, progress=True):
+                 criterion=None, tr_transform=None, vd_transform=None, sync_every=1, progress=True,
+                 capture_step=False):
         self.model = model
         self.optimizer = optimizer
         self.loss = loss if loss is not None else criterion
@@ -113,6 +114,11 @@ class Trainer():
         self.progress_bar = _NullBar()
         self._grad_sync = None
         self._scaler = None
+        # capture_step=True: training batches of the usual shape are replayed from a hipGraph of the whole step
+        # (graph.GraphedTrainStep - same numbers, the host only copies the batch in); needs optim.Adam, one process,
+        # bf16 / fp32 storage.  Off by default: the reference's loop is the eager one.
+        self.capture_step = bool(capture_step)
+        self._graphed = None
 
     # ------------------------------------------------------------------ small helpers
     def _split_indices(self):
@@ -159,6 +165,17 @@ class Trainer():
         pending.clear()
         return last
 
+    def _graphed_step(self):
+        if not self.capture_step or self._grad_sync is not None or self._scaler is not None:
+            return None
+        if self._graphed is None:
+            import graph as graph_mod
+            import optim as optim_mod
+            if not isinstance(self.optimizer, optim_mod.Adam):
+                raise TypeError("Trainer(capture_step=True) needs optim.Adam")
+            self._graphed = graph_mod.GraphedTrainStep(self.model, self.loss, self.optimizer)
+        return self._graphed
+
     def batch_loop(self, data_loader, is_train=True):
         results, pending = [], []
         self.progress_bar.reset(len(data_loader))
@@ -167,6 +184,22 @@ class Trainer():
         for batch_idx, batch in enumerate(data_loader):
             x = batch['image'].to(self.device, non_blocking=True)
             y = batch['label'].to(self.device, non_blocking=True)
+            graphed = self._graphed_step() if is_train else None
+            if graphed is not None:
+                self.model.train()
+                loss = graphed(x, y)
+                y_pred = graphed.logits
+                scalars = {'loss': loss.clone()}         # a static buffer: the next replay overwrites it
+                if self.metrics is not None:
+                    with torch.no_grad():
+                        for key, metric_fn in self.metrics.items():
+                            scalars[key] = metric_fn(y_pred, y)
+                pending.append({k: (v if torch.is_tensor(v) else torch.tensor(float(v))) for k, v in scalars.items()})
+                if len(pending) >= self.sync_every:
+                    last = self._flush(pending, results)
+                    self.progress_bar.set_postfix(last)
+                self.progress_bar.update()
+                continue
             if is_train:
                 self.model.train()
                 y_pred = self.model(x)

@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-torch-adam", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--launch", default="eager", choices=["graph", "eager"],
+                    help="graph: replay the step from a hipGraph captured after the warm-up (1 GPU, bf16/fp32, fused "
+                         "Adam); eager: issue every launch from Python")
     ap.add_argument("--eval-mode", action="store_true", help="dropout off")
     return ap.parse_args()
 
@@ -288,16 +291,34 @@ def main():
             return loss
         return step
 
-    step = make_step(opt)
+    eager_step = make_step(opt)
+    step = eager_step
+    # --launch graph (N = 1): the whole step (forward, loss, backward, fused Adam) is captured in a hipGraph after the
+    # warm-up and the timed region replays it - the same kernels on the same data (graph.py).  Measured: 20.13 ms per
+    # step either way - the step is device-bound; the replay frees the host (11 ms instead of 19 ms of enqueueing per
+    # step), it does not shorten the step, so the default stays the plain launch sequence.
+    use_graph = args.launch == "graph" and world == 1 and scaler is None and args.optimizer == "fused"
+    gstep = None
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    torch.cuda.reset_peak_memory_stats(dev)
+    if use_graph:
+        import graph as graph_mod
+        gstep = graph_mod.GraphedTrainStep(model, criterion, opt, warmup=max(1, args.warmup))
+
+        def step():
+            return gstep(x, y)
+        for _ in range(max(1, args.warmup) + 1):      # eager warm-up steps, then capture + first replay
+            step()
+    else:
+        for _ in range(args.warmup):
+            step()
     fence()
+    peak_mem_capture = torch.cuda.max_memory_allocated(dev)
     # the interpreter's full (generation-2) collection walks every object torch imported - ~90 ms, once, a few steps
     # into the process; park the startup objects in the permanent generation before the timed region
     gc.collect()
@@ -305,17 +326,35 @@ def main():
     probe = None
     if not args.no_probe and dtype != torch.float32:
         probe = ops.Probe(cin=args.features, cout=args.features, k=3, stride=1, extent=dims)
-        ops.set_probe(probe)
-    torch.cuda.reset_peak_memory_stats(dev)
+        if not use_graph:
+            ops.set_probe(probe)
+    if not use_graph:
+        torch.cuda.reset_peak_memory_stats(dev)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    host_dt = time.perf_counter() - t0          # the host is done enqueueing here; the device may still be running
     fence()
     dt = time.perf_counter() - t0
     ops.set_probe(None)
     loss_value = float(loss.item())
-    peak_mem = torch.cuda.max_memory_allocated(dev)
+    # a replay allocates nothing: the step's peak is the one seen while it was captured
+    peak_mem = peak_mem_capture if use_graph else torch.cuda.max_memory_allocated(dev)
+    eager_ms = eager_host_ms = None
+    if use_graph:
+        # the same steps issued launch by launch, right behind the timed replays: the eager figure for comparison, and
+        # the HIP-event timing of the roofline kernel (events recorded inside a captured graph cannot be read back)
+        if probe is not None:
+            ops.set_probe(probe)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            eager_step()
+        eager_host_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+        fence()
+        eager_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+        ops.set_probe(None)
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
@@ -332,6 +371,9 @@ def main():
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "per_gpu": total / world, "final_loss": loss_value, "peak_mem_gib": peak_mem / 2 ** 30,
+        "host_enqueue_ms_per_step": 1e3 * host_dt / args.steps,
+        "step_launch": "hipGraph replay of the captured step (graph.GraphedTrainStep)" if use_graph else
+                       "eager: ~550 launches per step issued from Python",
         "config": {"workload": "ResUnet3D(num_pool=%d, num_features=%d, in=1, out=%d) train step "
                                "(fwd+HybirdLoss+bwd+Adam), %dx1x%s per GPU, dropout %s%s" %
                                (args.pools, args.features, args.classes, args.batch, shape_txt,
@@ -340,6 +382,9 @@ def main():
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                    "optimizer": "optim.Adam (fused multi-tensor)" if args.optimizer == "fused" else "torch.optim.Adam"},
     }
+    if use_graph:
+        out["ms_per_step_eager"] = eager_ms
+        out["host_enqueue_ms_per_step_eager"] = eager_host_ms
     if world > 1:
         out["config"]["grad_exchange"] = ("RCCL all-reduce via ru3d_comm_allreduce, side HIP stream, 64 MiB buckets, "
                                           "%s transport" % args.grad_transport) if transport == "rccl" else \
@@ -384,6 +429,8 @@ def main():
     if world == 1 and args.optimizer == "fused" and not args.no_torch_adam:
         # the caller-owned optimizer of the reference scripts (nb_train_iia.py:18) on the same model
         topt = torch.optim.Adam(model.parameters(), lr=1e-4)
+        if gstep is not None:
+            gstep.release()
         tstep = make_step(topt)
         for _ in range(2):
             tstep()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define RU3D_VERSION 200
+#define RU3D_VERSION 201
 
 /* storage dtypes of activations / packed weights (accumulation is always fp32).  RU3D_F16 is the reference's
  * mixed-precision arithmetic (apex O1: fp16 convolutions with fp32 accumulation, trainer.py:492-493, 538-542) and
@@ -164,6 +164,11 @@ int ru3d_channel_sum(const ru3d_tensor* t, float* out, void* ws, size_t ws_bytes
 /* nn.Dropout3d(p) channel mask (network.py:397-398,412-413): scale[n*C+c] = keep ? 1/(1-p) : 0,
  * counter-based RNG keyed by (seed, offset). */
 int ru3d_dropout3d_scale(float* scale, int count, float p, uint64_t seed, uint64_t offset, void* stream);
+/* The same draw with the counter offset completed ON THE DEVICE: offset + *offset_base.  For a training step captured
+ * in a hipGraph - the launch arguments are frozen at capture; the host advances *offset_base between replays, so replay
+ * k draws exactly the masks the eager step k would have drawn. */
+int ru3d_dropout3d_scale_dev(float* scale, int count, float p, uint64_t seed, uint64_t offset,
+                             const uint64_t* offset_base, void* stream);
 
 /* Elementwise pieces of the attention gate (AttBlock, network.py:353-371: x = conv(x); g = conv(gate);
  * rate = sigmoid(conv(lrelu(x + g))); return x * rate) and of its backward; the convolutions are ru3d_conv3d_*.
@@ -268,6 +273,12 @@ typedef struct ru3d_adam_tensor {
 int ru3d_adam_multi(const ru3d_adam_tensor* tensors, const int32_t* block_map, int nblocks, int chunk_elems,
                     float lr, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
                     float grad_scale, void* stream);
+
+/* ru3d_adam_multi with the per-step scalars read from device memory - hyper[8] = {lr, beta1, beta2, eps, bias_corr1,
+ * bias_corr2, grad_scale, sqrtf(bias_corr2)} - so that a launch captured in a hipGraph follows the step count and the learning-rate
+ * schedule: the host rewrites the 32 bytes before each replay. */
+int ru3d_adam_multi_dev(const ru3d_adam_tensor* tensors, const int32_t* block_map, int nblocks, int chunk_elems,
+                        const float* hyper, void* stream);
 
 /* Dynamic loss scaling of the fp16 mode (the reference's apex O1: trainer.py:492-493 amp.scale_loss, 538-542
  * amp.initialize): every gradient named by the table (same layout as ru3d_adam_multi; only grad / count are read) is

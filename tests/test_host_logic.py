@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(N.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert N.lib.ru3d_version() == 200
+    assert N.lib.ru3d_version() == 201
     # pure host-side queries work without a device
     assert N.lib.ru3d_loss_state_bytes(3) > 0
     assert N.lib.ru3d_packed_weight_bytes(32, 32, 3, 1, N.ROLE_CONV_FWD, N.BF16) > 0
