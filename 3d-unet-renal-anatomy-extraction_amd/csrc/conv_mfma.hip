@@ -713,7 +713,7 @@ static void stats_slab_geom(const ConvGeom& g, int* gx, int* gy, int* cb) {
     if (slide64_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) {
         *gx = sp.grid;
         *gy = sp.ny;
-        *cb = 64;
+        *cb = g.Cout == 32 ? 32 : 64;
         return;
     }
     const S1Plan p = s1_plan(g.N, g.Do, g.Ho, g.Wo, g.Cout);

@@ -78,13 +78,20 @@ __device__ __forceinline__ void mfma16(f32x4& acc, const bf16x8& w, const bf16x8
     else asm volatile(RU3D_MFMA16_ASM " %0, %1, %2, %0" : "+v"(acc) : "a"(wi), "v"(xi));
 }
 
-template <bool HAS_RES, bool HAS_STATS>
+// VG = 1: the four waves are four groups of 16 output channels (64 per workgroup), each wave walks both W halves of
+// the column.  VG = 2 (Cout = 32: the decoder's 64 -> 32 conv on the full-resolution level): two channel groups x two
+// voxel groups - a wave owns one W half, so the workgroup still keeps four matrix pipes busy on 32 output channels.
+template <bool HAS_RES, bool HAS_STATS, int VG>
 __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a) {
     __shared__ __attribute__((aligned(16))) bf16 lds[RING * PLANE];
     __shared__ __attribute__((aligned(16))) bf16 est_s[4 * 128 * EP];   // epilogue patches (stored values), one per wave
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int co_w = blockIdx.y * 64 + wave * 16;      // first output channel of this wave
+    constexpr int NHF = VG == 1 ? 2 : 1;               // W halves a wave walks
+    constexpr int CB = VG == 1 ? 64 : 32;              // output channels per workgroup
+    const int cg = VG == 1 ? wave : (wave & 1);        // channel group of 16
+    const int hfw = VG == 1 ? 0 : (wave >> 1);         // VG = 2: the wave's W half
+    const int co_w = blockIdx.y * CB + cg * 16;        // first output channel of this wave
 
     // ---- weights: fragment (tap, ks32) of this wave's 16 couts, gathered from the 32x32x16 fragment order
     //   element (co, ci) of tap t lives at ((t * KS16 + ci / 16) * NTT + co / 32) * 64 + (co % 32) + 32 * ((ci / 8) & 1)
@@ -111,15 +118,15 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
     auto piece_dst = [&](int i) { return piece_row(i) * PITCH + ((tid + 256 * i) & 7) * 8; };
     // ---- fragment address of this lane: voxel (lane & 15) of a 16-voxel W-run, k-block lane >> 4; row, half, kw,
     // k-step and plane are compile-time offsets
-    const bf16* bl = lds + (lane & 15) * PITCH + (lane >> 4) * 8;
+    const bf16* bl = lds + ((lane & 15) + 16 * hfw) * PITCH + (lane >> 4) * 8;
 
-    // fused InstanceNorm statistics: slab[workgroup][wave][n][64][2]; a wave fills its own 16 channels, the rest of
+    // fused InstanceNorm statistics: slab[workgroup][wave][n][CB][2]; a wave fills its own 16 channels, the rest of
     // its row stays at the zeros the caller wrote
     float st1[8], st2[8];
     int cur_n = -1;
     auto stat_flush = [&]() {
         if (!HAS_STATS || cur_n < 0) return;
-        float* dst = a.stat_slab + ((((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * a.N + cur_n) * 64) * 2;
+        float* dst = a.stat_slab + ((((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * a.N + cur_n) * CB) * 2;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             float s1 = st1[i], s2 = st2[i];
@@ -129,14 +136,14 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
                 s2 += __shfl_xor(s2, o, 64);
             }
             if (lane < 2) {
-                const int c = wave * 16 + lane * 8 + i;
+                const int c = cg * 16 + lane * 8 + i;
                 dst[c * 2] = s1;
                 dst[c * 2 + 1] = s2;
             }
         }
     };
 
-    f32x4 acc[TH][2];           // [output row][W half]: one set - a tile goes to the patch as soon as its last MFMA is issued
+    f32x4 acc[TH][NHF];         // [output row][W half]: one set - a tile goes to the patch as soon as its last MFMA is issued
     bf16x8 xq[HH];              // activation fragments of one (group, W half): input rows 0..5
     bf16* est = est_s + wave * (128 * EP);
     // bias of the 4 channels this lane holds in the accumulator layout
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
         // a "pass" is one (group, W half): q = 2 g + hf, 36 per step, 12 MFMAs each
         auto frag_row = [&](auto phn, auto qc, auto rc) {
             constexpr int PHN = decltype(phn)::value, q = decltype(qc)::value, r = decltype(rc)::value;
-            constexpr int g = q >> 1, hf = q & 1;
+            constexpr int g = q / NHF, hf = q % NHF;
             constexpr int kd = g / 6, kw = (g % 6) >> 1, ks = g & 1;
             xq[r] = *reinterpret_cast<const bf16x8*>(bl + ((PHN + kd) & 3) * PLANE + (r * WW + kw + 16 * hf) * PITCH + ks * 32);
         };
@@ -221,9 +228,9 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
             for (int i = 0; i < 4; i++) v[i] = (bf16)(acc[m][hf][i] + bias4[i]);
             *reinterpret_cast<bf16x4*>(est + ((hf * TH + m) * 16 + (lane & 15)) * EP + 4 * (lane >> 4)) = v;
         };
-        auto epi_vox = [&](int sp, int p) {     // p = 0..3: patch rows 32 p + (lane >> 1); row = (hf * 4 + m) * 16 + w16
+        auto epi_vox = [&](int sp, int p) {     // p = 0..2 NHF - 1: patch rows 32 p + (lane >> 1); row = (hf * 4 + m) * 16 + w16
             const int row = 32 * p + (lane >> 1);
-            const int hf = row >> 6, m = (row >> 4) & 3;
+            const int hf = VG == 1 ? (row >> 6) : hfw, m = (row >> 4) & 3;
             return (((int64_t)n * a.D + d0 + sp) * a.H + h0 + m) * (int64_t)a.W + w0 + 16 * hf + (row & 15);
         };
         auto epi_row_load = [&](int p, bf16x8& rv) {
@@ -248,8 +255,9 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
                 *reinterpret_cast<bf16x8*>(ybase + epi_vox(sp, p) * a.ldy) = rv;
             }
         };
-        // the row phase of one plane as 8 pieces: (load, finish) x 4
-        auto epi_piece = [&](auto pc, int sp, bf16x8& rv, const bf16x8 (&rq)[4]) {
+        // the row phase of one plane as 4 NHF pieces: (load, finish) x 2 NHF
+        constexpr int NEP = 4 * NHF, NRQ = 2 * NHF;
+        auto epi_piece = [&](auto pc, int sp, bf16x8& rv, const bf16x8 (&rq)[NRQ]) {
             constexpr int p = decltype(pc)::value;
             if constexpr ((p & 1) == 0) epi_row_load(p >> 1, rv);
             else epi_row_finish(sp, p >> 1, rv, rq[p >> 1]);
@@ -259,21 +267,21 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
             constexpr int PH = decltype(phc)::value;
             const bool has_prev = s > 0, last = s == a.DL - 1;
             bf16x8 rv;
-            bf16x8 rq[4];
+            bf16x8 rq[NRQ];
             if constexpr (HAS_RES) {
                 if (has_prev) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++)
+                    for (int k = 0; k < NRQ; k++)
                         rq[k] = *reinterpret_cast<const bf16x8*>(rbase + epi_vox(s - 1, k) * a.ldr);
                 }
             }
             // wait states in front of the inline-asm MFMA block (see conv_slide.hip)
             asm volatile("s_nop 7\n\ts_nop 7");
-            static_for<0, 2 * NG>([&](auto qc) {
+            static_for<0, NHF * NG>([&](auto qc) {
                 constexpr int q = decltype(qc)::value;
-                constexpr int g = q >> 1, hf = q & 1;
+                constexpr int g = q / NHF, hf = q % NHF;
                 constexpr int kd = g / 6, kw = (g % 6) >> 1, ks = g & 1;
-                if constexpr (q == 22) __syncthreads();   // (in front of group 11) plane s+2, stored during the previous
+                if constexpr (q == 11 * NHF) __syncthreads();   // (in front of group 11) plane s+2, stored during the previous
                                                           // step, is complete; every wave is past kd = 0: the slot of
                                                           // plane s-1 is free
                 // walk the six input rows; row r feeds output rows m = r - kh (kh = 0..2)
@@ -296,17 +304,17 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
                             asm volatile("" : "+v"(acc[r - 3][hf]));
                             epi_write(r - 3, hf);
                         }
-                        if constexpr (hf == 1 && r == 1) {
+                        if constexpr (NHF == 2 && hf == 1 && r == 1) {
                             asm volatile("" : "+v"(acc[3][0]));
                             epi_write(3, 0);
                         }
-                        if constexpr (hf == 1 && r == 5) {
-                            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[3][1]));
-                            epi_write(3, 1);
+                        if constexpr (hf == NHF - 1 && r == 5) {
+                            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[3][hf]));
+                            epi_write(3, hf);
                         }
                     }
                     // row r is free: refill it for the next pass
-                    if constexpr (q + 1 < 2 * NG) {
+                    if constexpr (q + 1 < NHF * NG) {
                         frag_row(std::integral_constant<int, PH>{}, std::integral_constant<int, q + 1>{}, rc);
                     } else {
                         if (!last) frag_row(std::integral_constant<int, (PH + 1) & 3>{}, std::integral_constant<int, 0>{}, rc);
@@ -314,9 +322,9 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
                     // plane staging behind the barrier: piece i of plane s+3 goes to LDS in pass 22 + 2 i (row 1), piece i
                     // of plane s+4 is loaded into the freed registers one pass later (row 3); unconditional (clamped)
                     if constexpr (r == 1 && hf == 0 && g >= 11 && g < 11 + NSTG) store_piece(s + 3, (PH + 3) & 3, std::integral_constant<int, g - 11>{});
-                    if constexpr (r == 3 && hf == 1 && g >= 11 && g < 11 + NSTG) load_piece(s + 4, std::integral_constant<int, g - 11>{});
-                    // row phase of the previous plane: 8 pieces over passes 0, 2, .., 14 (row 4)
-                    if constexpr (r == 4 && hf == 0 && g < 8) {
+                    if constexpr (r == 3 && hf == NHF - 1 && g >= 11 && g < 11 + NSTG) load_piece(s + 4, std::integral_constant<int, g - 11>{});
+                    // row phase of the previous plane: its pieces over the first groups (row 4)
+                    if constexpr (r == 4 && hf == 0 && g < NEP) {
                         if (has_prev) epi_piece(std::integral_constant<int, g>{}, s - 1, rv, rq);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -334,14 +342,14 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
         }
         // the last plane of the unit has no next step to hide behind
         {
-            bf16x8 rq[4];
+            bf16x8 rq[NRQ];
             bf16x8 rv;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < NRQ; k++) {
                 const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
                 rq[k] = HAS_RES ? *reinterpret_cast<const bf16x8*>(rbase + epi_vox(a.DL - 1, k) * a.ldr) : z8;
             }
-            static_for<0, 8>([&](auto pc) { epi_piece(pc, a.DL - 1, rv, rq); });
+            static_for<0, NEP>([&](auto pc) { epi_piece(pc, a.DL - 1, rv, rq); });
         }
     }
     stat_flush();
@@ -351,8 +359,8 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
 // units = N x dsplit x (H/4) x (W/32) columns of DL = D/dsplit planes, times Cout/64 output slices (grid.y)
 bool slide64_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* out) {
     static const int mode = getenv("RU3D_CONV_SLIDE64") ? atoi(getenv("RU3D_CONV_SLIDE64")) : 1;
-    if (mode == 0 || Cin != 64 || (Cout != 64 && Cout != 128) || (H % TH) || (W % TW) || D < 4) return false;
-    const int ny = Cout / 64;
+    if (mode == 0 || Cin != 64 || (Cout != 32 && Cout != 64 && Cout != 128) || (H % TH) || (W % TW) || D < 4) return false;
+    const int ny = Cout == 32 ? 1 : Cout / 64;
     const int64_t cols = (int64_t)N * (H / TH) * (W / TW);
     int64_t best_cost = -1;
     int best = 0;
@@ -405,9 +413,16 @@ int conv_slide64_launch(const void* x, const void* w, const float* bias, const v
     a.flip = g.flip;
     a.cout_total = g.Cout;
     a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w; a.dsplit = p.dsplit; a.DL = p.DL; a.units = p.units;
-    if (res) hipLaunchKernelGGL((conv3_s1_slide64_kernel<true, false>), dim3(p.grid, p.ny), dim3(256), 0, st, a);
-    else if (stat_slab) hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, true>), dim3(p.grid, p.ny), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, false>), dim3(p.grid, p.ny), dim3(256), 0, st, a);
+    const dim3 grid(p.grid, p.ny), block(256);
+    if (g.Cout == 32) {
+        if (res) hipLaunchKernelGGL((conv3_s1_slide64_kernel<true, false, 2>), grid, block, 0, st, a);
+        else if (stat_slab) hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, true, 2>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, false, 2>), grid, block, 0, st, a);
+    } else {
+        if (res) hipLaunchKernelGGL((conv3_s1_slide64_kernel<true, false, 1>), grid, block, 0, st, a);
+        else if (stat_slab) hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, true, 1>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, false, 1>), grid, block, 0, st, a);
+    }
     return ru3d_check_launch("conv3_s1_slide64");
 }
 

@@ -33,7 +33,7 @@ def _close(a, b, rtol, atol, what):
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 32, 5, 9, 37), (1, 64, 64, 3, 10, 12), (1, 128, 64, 5, 5, 7),
-                                   (2, 32, 32, 64, 64, 64), (2, 32, 64, 32, 64, 64), (1, 64, 64, 16, 32, 32), (2, 64, 64, 32, 32, 64),
+                                   (2, 32, 32, 64, 64, 64), (2, 32, 64, 32, 64, 64), (1, 64, 64, 16, 32, 32), (2, 64, 64, 32, 32, 64), (2, 64, 32, 16, 32, 64),
                                    (1, 256, 256, 8, 8, 8)])
 def test_conv3_s1_fp16(shape):
     """3x3x3 stride-1 conv (halo-tile, producer/consumer, D-sliding and split-K kernels) with bias + residual, its
