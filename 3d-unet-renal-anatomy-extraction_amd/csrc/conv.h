@@ -90,7 +90,8 @@ size_t wgrad_mfma_ws_bytes(const WgradGeom& g);
 int wgrad_mfma_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, WgradGeom g,
                       hipStream_t st);
 
-// conv_slide.hip (3x3x3 stride-1, 32 -> 32 channels: D-sliding plane ring, weights resident in LDS)
+// conv_slide32.hip (3x3x3 stride-1, 32 -> 32 / 64 channels: D-sliding plane ring on v_mfma_f32_16x16x32, a wave = all 32
+// couts of a 4 x 16 quarter of the column, the whole weight resident in AGPRs)
 struct SlidePlan {
     int dsplit, DL, tiles_h, tiles_w, units, grid, ny;
 };

@@ -1470,8 +1470,10 @@ int conv_mfma_launch(const void* x, const void* w, const float* bias, const void
     {
         SlidePlan sp;
         if (slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) {
+            // 16-byte stores; a sample within the 30-bit element range of the staging loads' buffer offsets
             const bool aligned = (g.ldy % 8) == 0 && (!res || (g.ldr % 8) == 0) && aligned_to(y, 16) &&
-                                 (!res || aligned_to(res, 16));
+                                 (!res || aligned_to(res, 16)) && (g.ldx % 8) == 0 && aligned_to(x, 16) &&
+                                 (int64_t)g.Do * g.Ho * g.Wo * g.ldx < (1ll << 30);
             if (aligned) return conv_slide_launch(x, w, bias, res, y, g, stat_slab, st);
             // the statistics slab (size, layout) was planned for the sliding kernel's grid: falling back to the
             // producer/consumer kernel here would fill it with another geometry

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
         auto epi_piece = [&](auto pc, int sp, bf16x8& rv, const bf16x8 (&rq)[NRQ]) {
             constexpr int p = decltype(pc)::value;
             if constexpr ((p & 1) == 0) epi_row_load(p >> 1, rv);
-            else epi_row_finish(sp, p >> 1, rv, rq[p >> 1]);
+            else epi_row_finish(sp, p >> 1, rv, rq[(p >> 1) < NRQ ? (p >> 1) : 0]);
         };
 
         auto step = [&](auto phc, int s) {
@@ -321,8 +321,8 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
                     }
                     // plane staging behind the barrier: piece i of plane s+3 goes to LDS in pass 22 + 2 i (row 1), piece i
                     // of plane s+4 is loaded into the freed registers one pass later (row 3); unconditional (clamped)
-                    if constexpr (r == 1 && hf == 0 && g >= 11 && g < 11 + NSTG) store_piece(s + 3, (PH + 3) & 3, std::integral_constant<int, g - 11>{});
-                    if constexpr (r == 3 && hf == NHF - 1 && g >= 11 && g < 11 + NSTG) load_piece(s + 4, std::integral_constant<int, g - 11>{});
+                    if constexpr (r == 1 && hf == 0 && g >= 11 && g < 11 + NSTG) store_piece(s + 3, (PH + 3) & 3, std::integral_constant<int, (g >= 11 && g < 11 + NSTG ? g - 11 : 0)>{});
+                    if constexpr (r == 3 && hf == NHF - 1 && g >= 11 && g < 11 + NSTG) load_piece(s + 4, std::integral_constant<int, (g >= 11 && g < 11 + NSTG ? g - 11 : 0)>{});
                     // row phase of the previous plane: its pieces over the first groups (row 4)
                     if constexpr (r == 4 && hf == 0 && g < NEP) {
                         if (has_prev) epi_piece(std::integral_constant<int, g>{}, s - 1, rv, rq);

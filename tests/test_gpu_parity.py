@@ -42,7 +42,7 @@ def _close(a, b, rtol, atol=0.0, what=""):
 
 
 def test_library_loaded_from_tree():
-    assert N.lib.ru3d_version() == 200
+    assert N.lib.ru3d_version() == 201
     assert os.path.dirname(N.LIB_PATH).endswith("3d-unet-renal-anatomy-extraction_amd")
 
 

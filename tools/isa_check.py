@@ -7,7 +7,7 @@ Compiles every kernel source to gfx950 assembly (both storage-type builds), prin
 VGPR / AGPR / spill / scratch figures from the code-object metadata, and FAILS (exit 1) when
   * a kernel that issues inline-asm MFMAs (the D-sliding conv / weight-gradient kernels) has a `scratch_` instruction
     between its first and last `v_mfma` - the compiler's hazard recogniser cannot see those MFMAs' operands, so a
-    spill restore next to them is the hazard the hand-placed `s_nop`s do not cover (conv_slide.hip step()), or
+    spill restore next to them is the hazard the hand-placed `s_nop`s do not cover (wgrad_slide.hip), or
   * in the 64-channel sliding kernel (all weights in AGPRs, the allocator parks loop-invariant VGPRs in the remaining
     AGPRs and a few pointers in scratch) a `v_accvgpr_write` between the MFMAs targets an AGPR that an MFMA of the
     kernel reads, or a VALU instruction writes a source register of an MFMA one or two instructions ahead of it, or
@@ -24,14 +24,14 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "3d-unet-renal-anatomy-extraction_amd", "csrc")
-SRCS = ["conv_slide.hip", "conv_slide64.hip", "wgrad_slide.hip", "wgrad_s2.hip", "conv_mfma.hip", "small_convs.hip", "conv_generic.hip",
+SRCS = ["conv_slide32.hip", "conv_slide64.hip", "wgrad_slide.hip", "wgrad_s2.hip", "conv_mfma.hip", "small_convs.hip", "conv_generic.hip",
         "norm.hip", "loss.hip", "predict.hip", "comm.hip"]
-TWICE = {"conv_slide.hip", "conv_slide64.hip", "wgrad_slide.hip", "wgrad_s2.hip", "conv_mfma.hip", "small_convs.hip", "conv_generic.hip",
+TWICE = {"conv_slide32.hip", "conv_slide64.hip", "wgrad_slide.hip", "wgrad_s2.hip", "conv_mfma.hip", "small_convs.hip", "conv_generic.hip",
          "norm.hip"}
 # spilled VGPRs tolerated per kernel-name pattern (everything else: 0)
 ALLOW = [(r"conv3_s1_slide32_kernel", 64), (r"conv3_s1_slide64_kernel", 64), (r"conv3_s1_pc_kernel", 16), (r"wgrad3_s1_slide_kernel", 16)]
 NO_SCRATCH_IN_MFMA_SPAN = [r"conv3_s1_slide32_kernel", r"wgrad3_s1_slide_kernel"]
-NO_COPY_INTO_MFMA_OPERANDS = [r"conv3_s1_slide64_kernel"]
+NO_COPY_INTO_MFMA_OPERANDS = [r"conv3_s1_slide32_kernel", r"conv3_s1_slide64_kernel"]
 
 
 def regs_of(tok):
@@ -89,6 +89,7 @@ def copies_into_mfma_operands(lines, mf):
 def compile_asm(src, f16, tmp):
     out = os.path.join(tmp, src.replace(".hip", "_f16.s" if f16 else ".s"))
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-S",
+           *(["-fno-slp-vectorize"] if src in ("conv_slide32.hip", "conv_slide64.hip") else []),   # as the Makefile
            "-Wno-unused-function", "-Wno-pass-failed", os.path.join(CSRC, src), "-o", out]
     if f16:
         cmd.insert(1, "-DRU3D_STORAGE_F16")
