@@ -79,24 +79,13 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
     const int h = lane >> 5, cg = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = lane & 3;
     const int lane_off = q * 32 + 16 * cg + 4 * p4;   // row q of the 4x16 block, columns 4p..4p+3
 
-    // staging constants: X pieces c = tid + 256 i (row c >> 2 of the plane, piece c & 3); DY pieces likewise
-    int xrel[NSX], xzh[NSX], xzw[NSX];
-#pragma unroll
-    for (int i = 0; i < NSX; i++) {
-        const int c = tid + 256 * i;
-        const bool v = c < PROWS * 4;
-        const int r = v ? (c >> 2) : 0;
-        xzh[i] = v ? r / WW : -100000;
-        xzw[i] = r % WW;
-        xrel[i] = ((r / WW) * a.W + (r % WW)) * a.ldx + (c & 3) * 8;
-    }
-    int drel[NSD];
-#pragma unroll
-    for (int i = 0; i < NSD; i++) {
-        const int c = tid + 256 * i;
-        const int f = c >> 2;
-        drel[i] = ((f / TW) * a.W + (f % TW)) * a.lddy + (c & 3) * 8;
-    }
+    // staging: X pieces c = tid + 256 i (row c >> 2 of the plane, 16-byte piece c & 3); DY pieces likewise.  Loads go
+    // through buffer descriptors of the sample (byte offsets): a piece outside the volume carries an offset beyond the
+    // range and comes back as zeros, a plane outside the sample is switched off through the record count - no selects,
+    // no address clamps in the loop
+    bf16* const sdst = lds + (tid >> 2) * 32 + (tid & 3) * 8;
+    const int xplane_b = a.H * a.W * a.ldx * 2, dplane_b = a.H * a.W * a.lddy * 2;
+    const int xsample_b = a.D * xplane_b, dsample_b = a.D * dplane_b;
 
     for (int u = blockIdx.x; u < a.units; u += gridDim.x) {
         int t = u;
@@ -107,65 +96,63 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
         const int d0 = (t % a.dsplit) * a.DL;
         const int n = t / a.dsplit;
 
-        bool xok[NSX];
-        int xoff[NSX];
-        const int base_hw = ((h0 - 1) * a.W + (w0 - 1)) * a.ldx + cit * 32;
+        int xvoff[NSX], dvoff[NSD];
 #pragma unroll
         for (int i = 0; i < NSX; i++) {
-            const int gh = h0 - 1 + xzh[i], gw = w0 - 1 + xzw[i];
-            xok[i] = gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-            xoff[i] = xok[i] ? base_hw + xrel[i] : 0;     // out-of-range pieces read the plane's first bytes, zeroed at store
+            const int r = (tid >> 2) + 64 * i, zh = r / WW, zw = r - zh * WW;
+            const int gh = h0 - 1 + zh, gw = w0 - 1 + zw;
+            const bool ok = r < PROWS && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
+            xvoff[i] = ok ? ((gh * a.W + gw) * a.ldx + cit * 32 + (tid & 3) * 8) * 2 : (int)0x80000000;
         }
-        const int64_t xps = (int64_t)a.H * a.W * a.ldx, dps = (int64_t)a.H * a.W * a.lddy;
-        const bf16* dyb = a.dy + ((int64_t)n * a.D * a.H + h0) * (int64_t)a.W * a.lddy + (int64_t)w0 * a.lddy + cot * 32;
+#pragma unroll
+        for (int i = 0; i < NSD; i++) {
+            const int f = (tid >> 2) + 64 * i;
+            dvoff[i] = (((h0 + f / TW) * a.W + w0 + f % TW) * a.lddy + cot * 32 + (tid & 3) * 8) * 2;
+        }
+        const bf16* xs = a.x + (int64_t)n * a.D * (xplane_b / 2);
+        const bf16* ds = a.dy + (int64_t)n * a.D * (dplane_b / 2);
 
         bf16x8 sx[NSX], sd[NSD];
-        auto load_x = [&](int pr) {            // X plane d0 - 1 + pr
-            int d = d0 - 1 + pr;
-            d = d < 0 ? 0 : (d >= a.D ? a.D - 1 : d);
-            const bf16* src = a.x + ((int64_t)n * a.D + d) * xps;
-#pragma unroll
-            for (int i = 0; i < NSX; i++) sx[i] = *reinterpret_cast<const bf16x8*>(src + xoff[i]);
-        };
-        auto store_x = [&](int pr, int slot) {
+        auto load_x1 = [&](int pr, auto ic) {      // piece i of X plane d0 - 1 + pr
+            constexpr int i = decltype(ic)::value;
             const int d = d0 - 1 + pr;
             const bool dok = d >= 0 && d < a.D;
-#pragma unroll
-            for (int i = 0; i < NSX; i++) {
-                const int c = tid + 256 * i;
-                const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (xzh[i] >= 0) *reinterpret_cast<bf16x8*>(lds + slot * XPLANE + (c >> 2) * 32 + (c & 3) * 8) = (dok && xok[i]) ? sx[i] : z8;
-            }
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xs, (short)0, dok ? xsample_b : 0, 0x00020000);
+            sx[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, xvoff[i], dok ? d * xplane_b : 0, 0));
         };
-        auto load_d = [&](int s) {             // DY plane d0 + s
-            const bf16* src = dyb + (int64_t)(d0 + s) * dps;
-#pragma unroll
-            for (int i = 0; i < NSD; i++) sd[i] = *reinterpret_cast<const bf16x8*>(src + drel[i]);
+        auto store_x1 = [&](int slot, auto ic) {
+            constexpr int i = decltype(ic)::value;
+            // the last piece covers rows 320..383 of 340: threads 0..79 only
+            if (i * 64 + 64 <= PROWS || tid < (PROWS - i * 64) * 4)
+                *reinterpret_cast<bf16x8*>(sdst + slot * XPLANE + i * 64 * 32) = sx[i];
         };
-        auto store_d = [&](int buf) {
-#pragma unroll
-            for (int i = 0; i < NSD; i++) {
-                const int c = tid + 256 * i;
-                *reinterpret_cast<bf16x8*>(dbuf + buf * DPLANE + (c >> 2) * 32 + (c & 3) * 8) = sd[i];
-            }
+        auto load_d1 = [&](int s, auto ic) {       // piece i of DY plane d0 + s
+            constexpr int i = decltype(ic)::value;
+            const int d = d0 + s;
+            const bool dok = d < a.D;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ds, (short)0, dok ? dsample_b : 0, 0x00020000);
+            sd[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, dvoff[i], dok ? d * dplane_b : 0, 0));
         };
+        auto store_d1 = [&](int buf, auto ic) {
+            constexpr int i = decltype(ic)::value;
+            *reinterpret_cast<bf16x8*>(sdst + 4 * XPLANE + buf * DPLANE + i * 64 * 32) = sd[i];
+        };
+        auto load_x = [&](int pr) { static_for<0, NSX>([&](auto ic) { load_x1(pr, ic); }); };
+        auto store_x = [&](int slot) { static_for<0, NSX>([&](auto ic) { store_x1(slot, ic); }); };
+        auto load_d = [&](int s) { static_for<0, NSD>([&](auto ic) { load_d1(s, ic); }); };
+        auto store_d = [&](int buf) { static_for<0, NSD>([&](auto ic) { store_d1(buf, ic); }); };
 
         __syncthreads();   // the previous unit has left the ring
-        load_x(0); store_x(0, 0);
-        load_x(1); store_x(1, 1);
-        load_x(2); store_x(2, 2);
+        load_x(0); store_x(0);
+        load_x(1); store_x(1);
+        load_x(2); store_x(2);
         load_d(0); store_d(0);
         load_x(3);
-        if (a.DL > 1) load_d(1);
+        load_d(1);
         __syncthreads();
 
         auto step = [&](auto phc, int s) {
             constexpr int PH = decltype(phc)::value;
-            // the plane / DY rows loaded during the previous step go to the ring slot and DY buffer that died with it
-            if (s + 3 <= a.DL + 1) store_x(s + 3, (PH + 3) & 3);
-            if (s + 1 < a.DL) store_d((PH + 1) & 1);
-            if (s + 4 <= a.DL + 1) load_x(s + 4);
-            if (s + 2 < a.DL) load_d(s + 2);
             const bf16* db = dbuf + (PH & 1) * DPLANE;
             // fragments of k-step ks + 1 are fetched before the MFMAs of k-step ks (one wave per SIMD: nothing else
             // hides the LDS latency)
@@ -190,9 +177,22 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
 #pragma unroll
                 for (int t = 0; t < 7; t++)
                     acc[t] = RU3D_MFMA_32X32X16(aq[ks % 3][t], bq[ks % 3], acc[t], 0, 0, 0);
+                // Staging, one 16-byte piece behind each k-step's MFMAs (as one block at the top of the step it idled the
+                // matrix pipe for its ~120 instructions): the X plane / DY rows loaded during the previous step go to the
+                // ring slot and DY buffer that died with it, and the freed registers take the same piece of the next
+                // plane.  Unconditional: planes past the column are never read, loads past the sample return zeros.
+                if constexpr (ks < NSX) {
+                    store_x1((PH + 3) & 3, std::integral_constant<int, (ks < NSX ? ks : 0)>{});
+                    load_x1(s + 4, std::integral_constant<int, (ks < NSX ? ks : 0)>{});
+                } else if constexpr (ks < NSX + NSD) {
+                    store_d1((PH + 1) & 1, std::integral_constant<int, (ks >= NSX && ks < NSX + NSD ? ks - NSX : 0)>{});
+                    load_d1(s + 2, std::integral_constant<int, (ks >= NSX && ks < NSX + NSD ? ks - NSX : 0)>{});
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
-            __syncthreads();
+            // LDS-only barrier: the step's ring / DY stores are visible, every wave is done with the slots the next step
+            // overwrites (a __syncthreads() would also wait for the global loads just issued)
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         };
         for (int s4 = 0; s4 < a.DL; s4 += 4) {
             step(std::integral_constant<int, 0>{}, s4);
@@ -223,7 +223,8 @@ bool wgrad_slide_plan(const WgradGeom& g, WgradSlidePlan* out) {
     static const int mode = getenv("RU3D_WGRAD_SLIDE") ? atoi(getenv("RU3D_WGRAD_SLIDE")) : 1;
     if (!mode || g.k != 3 || g.stride != 1 || (g.Cin % 32) || (g.Cout % 32) || (g.Ho % TH) || (g.Wo % TW)) return false;
     if (g.Do != g.Di || g.Ho != g.Hi || g.Wo != g.Wi || (g.ldx % 8) || (g.lddy % 8)) return false;
-    if ((int64_t)g.Do * g.Ho * g.Wo * (g.ldx > g.lddy ? g.ldx : g.lddy) >= (1ll << 31)) return false;
+    // buffer-descriptor byte offsets of a sample, the top bit marking "outside the volume"
+    if ((int64_t)g.Do * g.Ho * g.Wo * (g.ldx > g.lddy ? g.ldx : g.lddy) >= (1ll << 30)) return false;
     const int pairs = (g.Cin / 32) * (g.Cout / 32);
     if (pairs > 8) return false;
     const int64_t cols = (int64_t)g.N * (g.Ho / TH) * (g.Wo / TW);
