@@ -1483,7 +1483,8 @@ int conv_mfma_launch(const void* x, const void* w, const float* bias, const void
         }
         if (slide64_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) {
             const bool aligned = (g.ldy % 8) == 0 && (!res || (g.ldr % 8) == 0) && aligned_to(y, 16) &&
-                                 (!res || aligned_to(res, 16));
+                                 (!res || aligned_to(res, 16)) && (g.ldx % 8) == 0 && aligned_to(x, 16) &&
+                                 (int64_t)g.Do * g.Ho * g.Wo * g.ldx < (1ll << 30);
             if (aligned) return conv_slide64_launch(x, w, bias, res, y, g, stat_slab, st);
             if (stat_slab)
                 return ru3d_fail(-1, "conv_mfma: fused statistics need y (and res) 16-byte aligned with a pitch that is "

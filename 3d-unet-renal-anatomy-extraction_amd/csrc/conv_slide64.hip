@@ -165,31 +165,32 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
         const int n = u / a.dsplit;
         const int d0 = dc * a.DL, h0 = th_i * TH, w0 = tw_i * TW;
 
-        int soff[NSTG];       // global offset of the piece inside a plane, -1: outside the volume (or no such piece)
-        const int base_hw = ((h0 - 1) * a.W + (w0 - 1)) * a.ldx;
+        // halo pieces of this column as byte offsets inside a plane; a piece outside the volume carries an offset beyond
+        // the buffer's range and the buffer load returns zeros, a plane outside the sample is switched off through the
+        // record count: no selects, no address clamps in the loop
+        const int plane_b = a.H * a.W * a.ldx * 2;
+        const int sample_b = a.D * plane_b;
+        int voff[NSTG];
 #pragma unroll
         for (int i = 0; i < NSTG; i++) {
             const int r = piece_row(i), zh = r / WW, zw = r - zh * WW;
             const int gh = h0 - 1 + zh, gw = w0 - 1 + zw;
             const bool okv = piece_valid(i) && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-            soff[i] = okv ? base_hw + (zh * a.W + zw) * a.ldx + ((tid + 256 * i) & 7) * 8 : -1;
+            voff[i] = okv ? ((gh * a.W + gw) * a.ldx + ((tid + 256 * i) & 7) * 8) * 2 : (int)0x80000000;
         }
-        const int64_t plane_stride = (int64_t)a.H * a.W * a.ldx;
+        const bf16* xs = a.x + (int64_t)n * a.D * (plane_b / 2);
 
         bf16x8 stg[NSTG];
         auto load_piece = [&](int pr, auto ic) {
             constexpr int i = decltype(ic)::value;
-            int d = d0 - 1 + pr;
-            d = d < 0 ? 0 : (d >= a.D ? a.D - 1 : d);
-            // out-of-range pieces read the plane's first bytes and are zeroed at the store
-            stg[i] = *reinterpret_cast<const bf16x8*>(a.x + ((int64_t)n * a.D + d) * plane_stride + (soff[i] < 0 ? 0 : soff[i]));
+            const int d = d0 - 1 + pr;
+            const bool dok = d >= 0 && d < a.D;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xs, (short)0, dok ? sample_b : 0, 0x00020000);
+            stg[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], dok ? d * plane_b : 0, 0));
         };
         auto store_piece = [&](int pr, int slot, auto ic) {
             constexpr int i = decltype(ic)::value;
-            const int d = d0 - 1 + pr;
-            const bool dok = d >= 0 && d < a.D;
-            const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (piece_valid(i)) *reinterpret_cast<bf16x8*>(lds + slot * PLANE + piece_dst(i)) = (dok && soff[i] >= 0) ? stg[i] : z8;
+            if (piece_valid(i)) *reinterpret_cast<bf16x8*>(lds + slot * PLANE + piece_dst(i)) = stg[i];
         };
         auto load_plane = [&](int pr) { static_for<0, NSTG>([&](auto ic) { load_piece(pr, ic); }); };
         auto store_plane = [&](int pr, int slot) { static_for<0, NSTG>([&](auto ic) { store_piece(pr, slot, ic); }); };
@@ -281,7 +282,8 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
                 constexpr int q = decltype(qc)::value;
                 constexpr int g = q / NHF, hf = q % NHF;
                 constexpr int kd = g / 6, kw = (g % 6) >> 1, ks = g & 1;
-                if constexpr (q == 11 * NHF) __syncthreads();   // (in front of group 11) plane s+2, stored during the previous
+                // LDS-only: a __syncthreads() would also drain vmcnt, i.e. wait for the epilogue stores just issued
+                if constexpr (q == 11 * NHF) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (in front of group 11) plane s+2, stored during the previous
                                                           // step, is complete; every wave is past kd = 0: the slot of
                                                           // plane s-1 is free
                 // walk the six input rows; row r feeds output rows m = r - kh (kh = 0..2)
@@ -399,7 +401,7 @@ int conv_slide64_launch(const void* x, const void* w, const float* bias, const v
     SlidePlan p;
     if (!slide64_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &p))
         return ru3d_fail(-1, "conv_slide64: shape not supported");
-    if ((int64_t)g.Do * g.Ho * g.Wo * g.ldx >= (1ll << 31)) return ru3d_fail(-1, "conv_slide64: sample too large");
+    if ((int64_t)g.Do * g.Ho * g.Wo * g.ldx >= (1ll << 30)) return ru3d_fail(-1, "conv_slide64: sample too large");
     if (res && stat_slab) return ru3d_fail(-1, "conv_slide64: residual and fused statistics cannot be combined");
     Slide64Args a;
     a.x = (const bf16*)x;
