@@ -786,7 +786,50 @@ struct DirectArgs {
     int k, stride, pad, flip, zero_far;
     int hd, hh, hw;          // transposed form: half-resolution extents ceil(Do/2)...
     int64_t total;           // gather: N*Do*Ho*Wo ; transposed: N*hd*hh*hw
+    int rows16;              // y (and res) allow 16-byte row pieces: pitch % 8 == 0, base 16-byte aligned
 };
+
+// Epilogue of one 32-position column tile held in 32x32x16 accumulators (lane -> position lane & 31, output channels
+// 8 q + 4 (lane >> 5) + i of tile t).  Written straight from that layout, a store instruction puts 8 bytes per lane at the
+// pitch of a voxel row: a 64- or 128-byte row arrives as 4-8 partial write requests.  Through a wave-private fp32 LDS
+// patch the lanes are re-dealt row-major - NT * 4 lanes x 16 bytes cover a position's NT * 32 channels - so every
+// request carries a whole row (and consecutive positions, where the form has them, one contiguous run).  Same
+// arithmetic as the direct form: (acc + bias) [zeroed on the far planes] + residual, rounded once.
+template <int NT>
+__device__ __forceinline__ void tile_epilogue_rows(const f32x16 (&acc)[NT], float* patch, int lane, int64_t vox_lane,
+                                                   bool far_lane, const float* bias, const bf16* res, int ldr, bf16* y,
+                                                   int ldy, int co_blk) {
+    constexpr int PP = NT * 32 + 4;          // floats per patch row
+    constexpr int PPR = NT * 4;              // 8-channel pieces per row
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            f32x4 v = {acc[t][q * 4], acc[t][q * 4 + 1], acc[t][q * 4 + 2], acc[t][q * 4 + 3]};
+            if (bias) v += *reinterpret_cast<const f32x4*>(bias + co_blk + t * 32 + 8 * q + 4 * (lane >> 5));
+            if (far_lane) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(patch + (lane & 31) * PP + t * 32 + 8 * q + 4 * (lane >> 5)) = v;
+        }
+    const int vlo = (int)(vox_lane & 0xffffffff), vhi = (int)(vox_lane >> 32);
+#pragma unroll
+    for (int it = 0; it < 32 * PPR / 64; it++) {
+        const int p = lane + 64 * it;
+        const int row = p / PPR, chunk = p % PPR;
+        const int64_t vox = ((int64_t)__shfl(vhi, row, 64) << 32) | (uint32_t)__shfl(vlo, row, 64);
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(patch + row * PP + chunk * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(patch + row * PP + chunk * 8 + 4);
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (vox >= 0) {
+            if (res) {
+                float r[8];
+                load_vec<bf16, 8>(res + vox * ldr + co_blk + chunk * 8, r);
+#pragma unroll
+                for (int i = 0; i < 8; i++) v[i] += r[i];
+            }
+            store_vec<bf16, 8>(y + vox * ldy + co_blk + chunk * 8, v);
+        }
+    }
+}
 
 template <int NT, bool TRANSPOSED>
 __global__ __launch_bounds__(256) void conv_direct_mfma_kernel(DirectArgs a) {
@@ -935,6 +978,7 @@ __device__ __attribute__((aligned(16))) bf16 g_zero16[8];
 template <int NT>
 __global__ __launch_bounds__(256) void conv_gather_mfma_kernel(DirectArgs a) {
     const bf16* const zero16 = g_zero16;
+    __shared__ __attribute__((aligned(16))) float patch_s[4][32 * (NT * 32 + 4)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NTT = a.Cout / 32, KS = a.Cin / 16;
@@ -1013,6 +1057,16 @@ __global__ __launch_bounds__(256) void conv_gather_mfma_kernel(DirectArgs a) {
         if (j < T) compute(x0, w0);
     }
 
+    if (a.rows16) {
+#pragma unroll
+        for (int m = 0; m < 2; m++) {
+            const int64_t vox = (((int64_t)n_[m] * a.Do + od[m]) * a.Ho + oh[m]) * a.Wo + ow[m];
+            const bool far = a.zero_far && (od[m] == a.Do - 1 || oh[m] == a.Ho - 1 || ow[m] == a.Wo - 1);
+            tile_epilogue_rows<NT>(acc[m], patch_s[wave], lane, valid[m] ? vox : -1, far, a.bias, a.res, a.ldr, a.y, a.ldy,
+                                   co_blk);
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < 2; m++) {
         if (!valid[m]) continue;
@@ -1399,6 +1453,7 @@ static int launch_direct(const void* x, const void* w, const float* bias, const 
     a.Cin = g.Cin; a.Cout = g.Cout; a.ldx = g.ldx; a.ldy = g.ldy; a.ldr = g.ldr;
     a.k = g.k; a.stride = g.stride; a.pad = g.pad; a.flip = g.flip; a.zero_far = g.zero_far;
     a.hd = (g.Do + 1) / 2; a.hh = (g.Ho + 1) / 2; a.hw = (g.Wo + 1) / 2;
+    a.rows16 = (g.ldy % 8) == 0 && (((uintptr_t)y) % 16) == 0 && (!res || ((g.ldr % 8) == 0 && (((uintptr_t)res) % 16) == 0));
     const bool nt2 = (g.Cout % 64) == 0;
     int64_t nblk;
     if (g.transposed) {
