@@ -1286,9 +1286,9 @@ __global__ __launch_bounds__(256) void conv_direct_ksplit_kernel(DirectArgs a) {
 template <int NT, int TD, int TH, int TW>
 __global__ __launch_bounds__(256, 2) void convt_tile_mfma_kernel(DirectArgs a) {
     extern __shared__ __attribute__((aligned(16))) bf16 tile_lds[];
-    static_assert(TD * TH * TW == 128, "128 half-resolution positions per workgroup");
+    static_assert((TD * TH * TW) % 32 == 0, "whole column tiles");
     constexpr int HD = TD + 1, HH = TH + 1, HW = TW + 1, ROWS = HD * HH * HW;
-    constexpr int MT = 4;                       // column tiles of 32 positions
+    constexpr int MT = TD * TH * TW / 32;       // column tiles of 32 positions: every weight fragment feeds MT MFMAs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int NTT = a.Cout / 32, KS = a.Cin / 16;
@@ -1306,15 +1306,31 @@ __global__ __launch_bounds__(256, 2) void convt_tile_mfma_kernel(DirectArgs a) {
     const int n = t / td_n;
 
     // ---- stage the input rows (zero outside the tensor)
+    // eight pieces per thread in flight: written as load -> store per piece the loop ran at one memory round trip per
+    // iteration (the store waits for its load), 16-31 of them per tile
     const int ppr = a.Cin / 8;                   // 16-byte pieces per row
-    for (int p = tid; p < ROWS * ppr; p += 256) {
-        const int r = p / ppr, piece = p - r * ppr;
-        const int zc = r % HW, zb = (r / HW) % HH, za = r / (HW * HH);
-        const int ia = a0 + za, ib = b0 + zb, ic = c0 + zc;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ia < a.Di && ib < a.Hi && ic < a.Wi)
-            v = *reinterpret_cast<const bf16x8*>(a.x + ((((int64_t)n * a.Di + ia) * a.Hi + ib) * a.Wi + ic) * a.ldx + piece * 8);
-        *reinterpret_cast<bf16x8*>(tile_lds + r * pitch + piece * 8) = v;
+    constexpr int SB = 8;
+    for (int p0 = tid; p0 < ROWS * ppr; p0 += 256 * SB) {
+        bf16x8 v[SB];
+        int dst[SB];
+#pragma unroll
+        for (int u = 0; u < SB; u++) {
+            const int p = p0 + 256 * u;
+            const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            v[u] = z8;
+            dst[u] = -1;
+            if (p < ROWS * ppr) {
+                const int r = p / ppr, piece = p - r * ppr;
+                const int zc = r % HW, zb = (r / HW) % HH, za = r / (HW * HH);
+                const int ia = a0 + za, ib = b0 + zb, ic = c0 + zc;
+                dst[u] = r * pitch + piece * 8;
+                if (ia < a.Di && ib < a.Hi && ic < a.Wi)
+                    v[u] = *reinterpret_cast<const bf16x8*>(a.x + ((((int64_t)n * a.Di + ia) * a.Hi + ib) * a.Wi + ic) * a.ldx + piece * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SB; u++)
+            if (dst[u] >= 0) *reinterpret_cast<bf16x8*>(tile_lds + dst[u]) = v[u];
     }
     __syncthreads();
 
@@ -1483,6 +1499,10 @@ static int launch_direct(const void* x, const void* w, const float* bias, const 
     if (tile_mode && g.transposed && g.k == 3 && g.pad == 1) {
         // (TD+1)(TH+1)(TW+1) rows of Cin*2+16 bytes must fit in LDS: Cin <= 256 with the 16-wide tile, 128 with the 32-wide
         if (a.hw >= 24 && g.Cin <= 128) {
+            // one cout tile: 256 positions per workgroup (8 column tiles per weight fragment) - the 110 KB of weights a
+            // workgroup pulls through its CU's ~10 B/clk are the larger part of what enters it
+            static const int big = getenv("RU3D_CONVT_BIG") ? atoi(getenv("RU3D_CONVT_BIG")) : 1;
+            if (!nt2 && big && g.Cin <= 64 && a.hh >= 4) return launch_convt_tile<1, 2, 4, 32>(a, g.N, st);
             return nt2 ? launch_convt_tile<2, 2, 2, 32>(a, g.N, st) : launch_convt_tile<1, 2, 2, 32>(a, g.N, st);
         }
         if (a.hw >= 12 && g.Cin <= 256) {

@@ -194,31 +194,51 @@ int stem_fwd_launch(const void* x, const void* w, const float* bias, void* y, co
 template <typename T, typename TO, int VEC>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const T* __restrict__ w,
                                                        const float* __restrict__ bias, TO* __restrict__ y, ConvGeom g) {
-    extern __shared__ float wl[];   // [Cin][4]
-    for (int i = threadIdx.x; i < g.Cin * 4; i += 256) wl[i] = to_f32<T>(w[i]);   // generic packing: [cin][cout_pad = 4]
-    __syncthreads();
-    const int G = g.Cin / VEC;      // power of two, <= 64
+    // Streaming kernel (reads |x|, writes 4-12 bytes per voxel): what it needs is bytes in flight.  A thread keeps its
+    // VEC x 4 weights in registers and handles HEAD_U voxels - all their 16-byte loads are issued before the first FMA -
+    // and after the xor-shuffles every lane of a voxel's group holds the sums, so lane cg stores channel cg: a wave's
+    // store instruction covers a contiguous run of logits instead of one lane in G writing three scattered values.
+    constexpr int HEAD_U = 4;
+    const int G = g.Cin / VEC;      // lanes per voxel: power of two, <= 64
+    const int cg = threadIdx.x % G;
+    const int slots = 256 / G;      // voxels per workgroup and round
+    float wr[VEC][4];
+#pragma unroll
+    for (int i = 0; i < VEC; i++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) wr[i][c] = to_f32<T>(w[(cg * VEC + i) * 4 + c]);   // generic packing: [cin][cout_pad = 4]
     const int64_t total = (int64_t)g.N * g.Do * g.Ho * g.Wo;
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t vo = gid / G;
-    const int cg = (int)(gid % G);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (vo < total) {
-        float xv[VEC];
-        load_vec<T, VEC>(x + vo * g.ldx + cg * VEC, xv);
+    const int64_t v0 = (int64_t)blockIdx.x * (slots * HEAD_U) + threadIdx.x / G;
+    float xv[HEAD_U][VEC];
 #pragma unroll
-        for (int i = 0; i < VEC; i++) {
-            const float* wr = wl + (cg * VEC + i) * 4;
+    for (int u = 0; u < HEAD_U; u++) {
+        const int64_t vo = v0 + u * slots;
+        if (vo < total) load_vec<T, VEC>(x + vo * g.ldx + cg * VEC, xv[u]);
+        else
 #pragma unroll
-            for (int c = 0; c < 4; c++) acc[c] = fmaf(xv[i], wr[c], acc[c]);
+            for (int i = 0; i < VEC; i++) xv[u][i] = 0.f;
+    }
+    const float bsel = (bias && cg < g.Cout) ? bias[cg] : 0.f;
+#pragma unroll
+    for (int u = 0; u < HEAD_U; u++) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < VEC; i++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c] = fmaf(xv[u][i], wr[i][c], acc[c]);
+        for (int o = 1; o < G; o <<= 1) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[c] += __shfl_xor(acc[c], o, 64);
         }
-    }
-    for (int o = 1; o < G; o <<= 1) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) acc[c] += __shfl_xor(acc[c], o, 64);
-    }
-    if (vo < total && cg == 0) {
-        for (int c = 0; c < g.Cout; c++) y[vo * g.ldy + c] = from_f32<TO>(acc[c] + (bias ? bias[c] : 0.f));
+        const int64_t vo = v0 + u * slots;
+        if (vo < total) {
+            if (G >= g.Cout) {
+                const float mine = cg == 0 ? acc[0] : (cg == 1 ? acc[1] : (cg == 2 ? acc[2] : acc[3]));
+                if (cg < g.Cout) y[vo * g.ldy + cg] = from_f32<TO>(mine + bsel);
+            } else if (cg == 0) {
+                for (int c = 0; c < g.Cout; c++) y[vo * g.ldy + c] = from_f32<TO>(acc[c] + (bias ? bias[c] : 0.f));
+            }
+        }
     }
 }
 
@@ -232,11 +252,11 @@ bool head_fwd_eligible(const ConvGeom& g, int dtype, const void* res) {
 int head_fwd_launch(const void* x, const void* w, const float* bias, void* y, const ConvGeom& g, int dtype,
                     int y_dtype, hipStream_t st) {
     const int vec = dtype == RU3D_BF16 ? 8 : 4;
-    const int64_t total = (int64_t)g.N * g.Do * g.Ho * g.Wo * (g.Cin / vec);
-    const int64_t blocks = (total + 255) / 256;
+    const int64_t per_block = (256 / (g.Cin / vec)) * 4;      // voxels per workgroup: slots x HEAD_U
+    const int64_t blocks = ((int64_t)g.N * g.Do * g.Ho * g.Wo + per_block - 1) / per_block;
     if (blocks > 0x7fffffff) return ru3d_fail(-1, "head_fwd: grid too large");
     if (((uintptr_t)x) % 16) return ru3d_fail(-1, "head_fwd: x must be 16-byte aligned");
-    const size_t lds = (size_t)g.Cin * 4 * sizeof(float);
+    const size_t lds = 0;
     dim3 grid((unsigned)blocks);
     if (dtype == RU3D_F32 && y_dtype == RU3D_F32)
         hipLaunchKernelGGL((head_fwd_kernel<float, float, 4>), grid, dim3(256), lds, st, (const float*)x,
@@ -534,15 +554,26 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const T* __restrict__ x
 #pragma unroll
         for (int c = 0; c < 4; c++) acc[i][c] = 0.f;
     if (active) {
-        for (int64_t p = p0 + vl; p < p1; p += vpb) {
-            float xv[VEC], dv[4];
-            load_vec<T, VEC>(x + p * g.ldx + cg * VEC, xv);
+        // four positions per round, all their loads issued before the first FMA (a streaming kernel: what it needs is
+        // bytes in flight; positions past the span read position p0 and contribute zeros)
+        constexpr int WU = 4;
+        for (int64_t p = p0 + vl; p < p1; p += (int64_t)WU * vpb) {
+            float xv[WU][VEC], dv[WU][4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) dv[c] = c < g.Cout ? to_f32<T>(dy[p * g.lddy + c]) : 0.f;
+            for (int u = 0; u < WU; u++) {
+                const int64_t pu = p + (int64_t)u * vpb;
+                const bool ok = pu < p1;
+                const int64_t pp = ok ? pu : p0;
+                load_vec<T, VEC>(x + pp * g.ldx + cg * VEC, xv[u]);
 #pragma unroll
-            for (int i = 0; i < VEC; i++)
+                for (int c = 0; c < 4; c++) dv[u][c] = (ok && c < g.Cout) ? to_f32<T>(dy[pp * g.lddy + c]) : 0.f;
+            }
 #pragma unroll
-                for (int c = 0; c < 4; c++) acc[i][c] = fmaf(xv[i], dv[c], acc[i][c]);
+            for (int u = 0; u < WU; u++)
+#pragma unroll
+                for (int i = 0; i < VEC; i++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc[i][c] = fmaf(xv[u][i], dv[u][c], acc[i][c]);
         }
     }
 #pragma unroll
