@@ -1,15 +1,14 @@
-"""Host-side profile of the training step (GPU box): where does the Python time of one step go?
-    python tools/hostprof.py [steps]"""
-import cProfile, io, os, pstats, runpy, sys
+"""Where the host's time per training step goes: cProfile over bench.py's timed steps (run on the GPU box)."""
+import cProfile, pstats, sys, os, io
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.argv = ["bench.py", "--steps", sys.argv[1] if len(sys.argv) > 1 else "10", "--warmup", "3", "--no-cpu-baseline", "--no-probe"]
+sys.path.insert(0, ROOT)
+sys.argv = ["bench.py", "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-parity", "--no-torch-adam", "--no-probe"]
+import bench
 pr = cProfile.Profile()
 pr.enable()
-try:
-    runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
-except SystemExit:
-    pass
+bench.main()
 pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
-print(s.getvalue()[:6000])
+st = pstats.Stats(pr, stream=s)
+st.sort_stats("tottime").print_stats(45)
+print(s.getvalue()[:9000])
