@@ -70,6 +70,9 @@ SIGNATURES = {
     "ru3d_instnorm_stats": (_i, [_P, _vp, _vp, _vp, _vp, _sz, _f, _i, _vp]),
     "ru3d_in_lrelu_fwd": (_i, [_P, _vp, _vp, _P, _P, _f, _i, _vp]),
     "ru3d_in_lrelu_bwd": (_i, [_P, _P, _P, _vp, _vp, _P, _P, _vp, _sz, _f, _i, _vp, _i, _vp]),
+    "ru3d_in_lrelu_bwd_apply": (_i, [_P, _P, _vp, _vp, _vp, _P, _f, _i, _i, _vp]),
+    "ru3d_conv3d_dgrad_in_bwd_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),
+    "ru3d_conv3d_dgrad_in_bwd": (_i, [_P, _vp, _P, _vp, _vp, _P, _P, _i, _i, _f, _i, _vp, _sz, _vp]),
     "ru3d_channel_sum": (_i, [_P, _vp, _vp, _sz, _i, _vp]),
     "ru3d_dropout3d_scale": (_i, [_vp, _i, _f, _u64, _u64, _vp]),
     "ru3d_dropout3d_scale_dev": (_i, [_vp, _i, _f, _u64, _u64, _vp, _vp]),

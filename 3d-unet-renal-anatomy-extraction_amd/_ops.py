@@ -254,6 +254,22 @@ def conv_dgrad(dy, pw, in_shape, k, stride, res=None):
     return dx
 
 
+def conv_dgrad_in_bwd(dy, pw, act, mean, scale, k=3, stride=1):
+    """da = conv^T(dy) followed by the InstanceNorm + LeakyReLU backward of act = lrelu(IN(y)): returns d/dy.  On the
+    sliding-kernel shapes the backward's two sums come out of the conv's epilogue (ru3d_conv3d_dgrad_in_bwd)."""
+    n, c, d, h, w = act.shape
+    da = N.new_act(n, c, d, h, w, dy.dtype, dy.device)
+    dyn = N.new_act(n, c, d, h, w, dy.dtype, dy.device)
+    ddy, dact, dda, ddyn = desc(dy), desc(act), desc(da), desc(dyn)
+    code = N.dtype_code(dy.dtype)
+    need = N.lib.ru3d_conv3d_dgrad_in_bwd_workspace_bytes(ref(ddy), ref(dda), k, stride, code)
+    ws = N.workspace(need, dy.device)
+    check(N.lib.ru3d_conv3d_dgrad_in_bwd(ref(ddy), ptr(pw), ref(dact), ptr(mean), ptr(scale), ref(dda), ref(ddyn), k,
+                                         stride, LRELU_SLOPE, code, ptr(ws), ws.numel(), stream()),
+          "conv3d_dgrad_in_bwd")
+    return dyn
+
+
 def conv_wgrad(x, dy, k, stride):
     cout, cin = dy.shape[1], x.shape[1]
     dw = torch.empty((cout, cin, k, k, k), dtype=torch.float32, device=x.device)
@@ -694,10 +710,10 @@ class ResBlockFn(torch.autograd.Function):
                 gws = unpad_wgrad(conv_wgrad(x, gpre, 1, stride), cout, cin, cout_seg, cin_seg)
                 gbs = gbs_sum[:cout]
         gb2 = None   # a bias that feeds InstanceNorm has an identically zero gradient: reported as "no gradient"
-        da1 = conv_dgrad(dy2, pw2d, tuple(a1.shape), 3, 1)
-        del dy2
-        dy1, _ = in_lrelu_bwd(da1, a1, y1, mean1, scale1)
-        del da1, a1, y1
+        # conv2's input gradient and the IN1 + LeakyReLU backward in one call: on the sliding-kernel shapes the backward's
+        # sums are taken in the conv's epilogue
+        dy1 = conv_dgrad_in_bwd(dy2, pw2d, a1, mean1, scale1)
+        del dy2, a1, y1
         with _OnSide(dev):
             gw1 = unpad_wgrad(conv_wgrad(x, dy1, 3, stride), cout, cin, cout_seg, cin_seg)
         gb1 = None

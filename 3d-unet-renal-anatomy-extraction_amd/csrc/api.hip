@@ -328,6 +328,71 @@ extern "C" int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, co
     return run_conv(dy, w_packed, nullptr, res, dx, k, stride, 1, 0, 0, dtype, dtype, as_stream(stream));
 }
 
+// ---- conv input gradient followed by the InstanceNorm + LeakyReLU backward of the tensor it differentiates
+static ConvGeom dgrad_s1_geom(const ru3d_tensor* dy, const ru3d_tensor* da, int k) {
+    ConvGeom g = fwd_geom(dy, da, k, 1);
+    g.flip = 1;
+    return g;
+}
+
+static bool dgrad_in_bwd_fused(const ru3d_tensor* dy, const ru3d_tensor* da, int k, int stride, int dtype) {
+    static const int mode = getenv("RU3D_DGRAD_IN_FUSE") ? atoi(getenv("RU3D_DGRAD_IN_FUSE")) : 1;
+    if (!mode || k != 3 || stride != 1 || dtype == RU3D_F32) return false;
+    const ConvGeom g = dgrad_s1_geom(dy, da, k);
+    return mfma_conv_eligible(g.Cin, g.Cout, k, dtype, dtype) && mfma_conv_can_fuse_bwd_sums(g) &&
+           (da->ld % 8) == 0 && (dy->ld % 8) == 0;
+}
+
+extern "C" size_t ru3d_conv3d_dgrad_in_bwd_workspace_bytes(const ru3d_tensor* dy, const ru3d_tensor* da, int k,
+                                                           int stride, int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_dgrad_in_bwd_workspace_bytes_f16(dy, da, k, stride, dtype));
+    if (!tensor_ok(dy) || !tensor_ok(da)) return 0;
+    size_t need = ru3d_reduce_workspace_bytes(da);
+    if (dgrad_in_bwd_fused(dy, da, k, stride, dtype)) {
+        // slab of per-(workgroup, wave) sums, then m12[n][c][2]
+        const size_t slab = (mfma_conv_stats_slab_bytes(dgrad_s1_geom(dy, da, k)) + 255) / 256 * 256;
+        const size_t fused = slab + (size_t)da->n * da->c * 2 * sizeof(float);
+        if (fused > need) need = fused;
+    }
+    if (stride == 1) {
+        const size_t conv_ws = ru3d_conv3d_workspace_bytes(dy, da, k, 1, dtype);
+        if (conv_ws > need) need = conv_ws;
+    }
+    return need;
+}
+
+extern "C" int ru3d_conv3d_dgrad_in_bwd(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* act,
+                                        const float* mean, const float* scale, const ru3d_tensor* da,
+                                        const ru3d_tensor* dyn, int k, int stride, float slope, int dtype, void* ws,
+                                        size_t ws_bytes, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_dgrad_in_bwd_f16(dy, w_packed, act, mean, scale, da, dyn, k, stride, slope, dtype, ws, ws_bytes, stream));
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(tensor_ok(dy) && tensor_ok(act) && tensor_ok(da) && tensor_ok(dyn) && w_packed && mean && scale && ws,
+                 "conv3d_dgrad_in_bwd: bad argument");
+    RU3D_REQUIRE(res_ok(act, da) && res_ok(dyn, da), "conv3d_dgrad_in_bwd: act / dyn do not have the shape of da");
+    RU3D_REQUIRE(ws_bytes >= ru3d_conv3d_dgrad_in_bwd_workspace_bytes(dy, da, k, stride, dtype),
+                 "conv3d_dgrad_in_bwd: workspace too small");
+    if (dgrad_in_bwd_fused(dy, da, k, stride, dtype) && (act->ld % 8) == 0 && (((uintptr_t)act->ptr) % 16) == 0 &&
+        (((uintptr_t)da->ptr) % 16) == 0 && (((uintptr_t)dy->ptr) % 16) == 0) {
+        RU3D_REQUIRE(da->n == dy->n && da->d == dy->d && da->h == dy->h && da->w == dy->w, "conv3d_dgrad_in_bwd: extents mismatch");
+        const ConvGeom g = dgrad_s1_geom(dy, da, k);
+        const size_t slab = (mfma_conv_stats_slab_bytes(g) + 255) / 256 * 256;
+        float* m12 = (float*)((char*)ws + slab);
+        hipError_t e = hipMemsetAsync(ws, 0, slab, as_stream(stream));   // workgroups that never touch a sample add 0
+        if (e != hipSuccess) return ru3d_fail((int)e, "conv3d_dgrad_in_bwd: memset failed: %s", hipGetErrorString(e));
+        int rc = conv_mfma_launch(dy->ptr, w_packed, nullptr, nullptr, da->ptr, g, as_stream(stream), (float*)ws, nullptr, 0,
+                                  act->ptr, act->ld, slope);
+        if (rc) return rc;
+        rc = mfma_conv_bwd_sums_finalize(g, (const float*)ws, m12, as_stream(stream));
+        if (rc) return rc;
+        return ru3d_in_lrelu_bwd_apply(da, act, mean, scale, m12, dyn, slope, 0, dtype, stream);
+    }
+    // not a shape the sliding kernel takes: the two entry points one after the other (they share the workspace in stream order)
+    int rc = ru3d_conv3d_dgrad(dy, w_packed, nullptr, da, k, stride, dtype, ws, ws_bytes, stream);
+    if (rc) return rc;
+    return ru3d_in_lrelu_bwd(da, act, act, mean, scale, dyn, nullptr, ws, ws_bytes, slope, 0, nullptr, dtype, stream);
+}
+
 static WgradGeom make_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, int k, int stride) {
     WgradGeom g;
     g.N = x->n;

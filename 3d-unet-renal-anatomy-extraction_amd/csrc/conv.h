@@ -79,12 +79,17 @@ size_t mfma_packed_bytes(int cin, int cout, int taps);
 int pack_mfma_launch(const float* src, void* dst, int cin, int cout, int taps, int64_t s_o, int64_t s_i, int flip,
                      hipStream_t st);
 int conv_mfma_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
-                     hipStream_t st, float* stat_slab = nullptr, void* ws = nullptr, size_t ws_bytes = 0);
+                     hipStream_t st, float* stat_slab = nullptr, void* ws = nullptr, size_t ws_bytes = 0,
+                     const void* bst_act = nullptr, int bst_ld = 0, float slope = 0.f);
 size_t conv_mfma_ws_bytes(const ConvGeom& g);
 bool mfma_conv_can_fuse_stats(const ConvGeom& g);
 size_t mfma_conv_stats_slab_bytes(const ConvGeom& g);
 int mfma_conv_stats_finalize(const ConvGeom& g, const float* slab, const float* drop, float eps, float* mean,
                              float* scale, hipStream_t st);
+// the sliding 32-channel kernel can take the InstanceNorm + LeakyReLU backward sums of its output (input-gradient role)
+bool mfma_conv_can_fuse_bwd_sums(const ConvGeom& g);
+// slab of backward sums -> m12[n][c] = (mean g', mean g' xhat)
+int mfma_conv_bwd_sums_finalize(const ConvGeom& g, const float* slab, float* m12, hipStream_t st);
 bool mfma_wgrad_eligible(const WgradGeom& g, int dtype);
 size_t wgrad_mfma_ws_bytes(const WgradGeom& g);
 int wgrad_mfma_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, WgradGeom g,
@@ -96,8 +101,10 @@ struct SlidePlan {
     int dsplit, DL, tiles_h, tiles_w, units, grid, ny;
 };
 bool slide_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* out);
+// bst_act != NULL (input-gradient role): the slab receives the InstanceNorm + LeakyReLU backward sums of the output
+// against the activation bst_act (pitch bst_ld) instead of the forward statistics
 int conv_slide_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
-                      float* stat_slab, hipStream_t st);
+                      float* stat_slab, hipStream_t st, const void* bst_act = nullptr, int bst_ld = 0, float slope = 0.f);
 
 // conv_slide64.hip (3x3x3 stride-1, 64 -> 64 / 128 channels: the same design on v_mfma_f32_16x16x32, a wave = 16 couts)
 bool slide64_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* out);

@@ -747,14 +747,35 @@ __global__ __launch_bounds__(256) void stats_slab_finalize_kernel(const float* _
     }
     const double t1 = wave_sum_d(a1), t2 = wave_sum_d(a2);   // xor-butterfly: fixed order
     if (lane == 0 && c < C) {
+        const int i = n * C + c;
+        if (!scale) {            // backward sums: mean[] receives m12 = (mean g', mean g' xhat)
+            mean[2 * i] = (float)(t1 * invV);
+            mean[2 * i + 1] = (float)(t2 * invV);
+            return;
+        }
         const double m = t1 * invV;
         double var = t2 * invV - m * m;
         if (var < 0.0) var = 0.0;
-        const int i = n * C + c;
         const double sdrop = drop ? (double)drop[i] : 1.0;
         mean[i] = (float)m;
         scale[i] = (float)(sdrop / sqrt(sdrop * sdrop * var + (double)eps));
     }
+}
+
+bool mfma_conv_can_fuse_bwd_sums(const ConvGeom& g) {
+    if (!(g.k == 3 && g.stride == 1 && !g.transposed && g.Cin == 32)) return false;
+    SlidePlan sp;
+    return slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp);
+}
+
+int mfma_conv_bwd_sums_finalize(const ConvGeom& g, const float* slab, float* m12, hipStream_t st) {
+    int gx, gy, cb;
+    stats_slab_geom(g, &gx, &gy, &cb);
+    dim3 grid((g.Cout + 3) / 4, g.N);
+    const double invV = 1.0 / ((double)g.Do * g.Ho * g.Wo);
+    hipLaunchKernelGGL(stats_slab_finalize_kernel, grid, dim3(256), 0, st, slab, gx, cb, g.N, g.Cout, invV,
+                       (const float*)nullptr, 0.f, m12, (float*)nullptr);
+    return ru3d_check_launch("bwd_sums_slab_finalize");
 }
 
 int mfma_conv_stats_finalize(const ConvGeom& g, const float* slab, const float* drop, float eps, float* mean,
@@ -1533,11 +1554,14 @@ static bool aligned_to(const void* p, size_t a) { return (((uintptr_t)p) % a) ==
 bool mfma_conv_geometry_ok(const ConvGeom& g) { return !g.transposed || g.stride == 2; }
 
 int conv_mfma_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
-                     hipStream_t st, float* stat_slab, void* ws, size_t ws_bytes) {
+                     hipStream_t st, float* stat_slab, void* ws, size_t ws_bytes, const void* bst_act, int bst_ld,
+                     float slope) {
     if (!mfma_conv_geometry_ok(g)) return ru3d_fail(-1, "conv_mfma: geometry not supported");
     if ((g.ldx % 8) || (g.ldy % 4) || (res && (g.ldr % 4)) || !aligned_to(x, 16) || !aligned_to(y, 8) ||
         (res && !aligned_to(res, 8)) || (bias && !aligned_to(bias, 16)) || !aligned_to(w, 16))
         return ru3d_fail(-1, "conv_mfma: operands must be 16-byte (x, w, bias) / 8-byte (y, res) aligned");
+    if (bst_act && !mfma_conv_can_fuse_bwd_sums(g))
+        return ru3d_fail(-1, "conv_mfma: fused backward sums are not available for this shape");
     if (!(g.k == 3 && g.stride == 1 && !g.transposed && (g.Cin % 32) == 0)) {
         if (stat_slab) return ru3d_fail(-1, "conv_mfma: fused statistics not available for this form");
         return launch_direct(x, w, bias, res, y, g, st);
@@ -1549,7 +1573,9 @@ int conv_mfma_launch(const void* x, const void* w, const float* bias, const void
             const bool aligned = (g.ldy % 8) == 0 && (!res || (g.ldr % 8) == 0) && aligned_to(y, 16) &&
                                  (!res || aligned_to(res, 16)) && (g.ldx % 8) == 0 && aligned_to(x, 16) &&
                                  (int64_t)g.Do * g.Ho * g.Wo * g.ldx < (1ll << 30);
-            if (aligned) return conv_slide_launch(x, w, bias, res, y, g, stat_slab, st);
+            if (aligned && (!bst_act || ((bst_ld % 8) == 0 && aligned_to(bst_act, 16))))
+                return conv_slide_launch(x, w, bias, res, y, g, stat_slab, st, bst_act, bst_ld, slope);
+            if (bst_act) return ru3d_fail(-1, "conv_mfma: the fused backward sums need 16-byte aligned operands");
             // the statistics slab (size, layout) was planned for the sliding kernel's grid: falling back to the
             // producer/consumer kernel here would fill it with another geometry
             if (stat_slab)

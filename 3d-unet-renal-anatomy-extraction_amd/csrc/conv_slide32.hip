@@ -57,6 +57,7 @@ struct Slide32Args {
     int ldx, ldy, ldr;
     int flip;
     int cout_total;                       // Cout of the conv (32 per grid.y slice)
+    float slope, inv_slope;               // HAS_BST: LeakyReLU slope of the activation being differentiated
     int tiles_h, tiles_w, dsplit, DL, units;
 #ifdef RU3D_SLIDE_STAMPS
     long long* stamps;
@@ -103,7 +104,11 @@ __device__ __forceinline__ void mfma16(f32x4& acc, const bf16x8& w, const bf16x8
 // column (pointers and accumulators carry over), so there is no per-step condition and no separate tail except once at
 // the end of the workgroup; the workgroup's very first step "finishes" garbage onto plane 0 of its first column, which
 // step 1 overwrites with the real values (same lanes, program order), and the statistics are reset behind it.
-template <bool HAS_RES, bool HAS_STATS>
+// HAS_BST (input-gradient role in front of an InstanceNorm + LeakyReLU backward, reference network.py:411-416): the
+// conv output IS the gradient wrt the activation a = lrelu(xhat), and the two sums that backward needs,
+// sum g' and sum g' * xhat with g' = g * lrelu'(a), xhat recovered from a, are taken in the row phase - `res` / `ldr`
+// carry the activation, the statistics slab the sums: the separate reduction pass over (g, a) disappears.
+template <bool HAS_RES, bool HAS_STATS, bool HAS_BST = false>
 __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a) {
     __shared__ __attribute__((aligned(16))) bf16 lds[RING * PLANE];
     __shared__ __attribute__((aligned(16))) bf16 est_s[4 * 64 * EP];    // epilogue patches (stored values), one per wave
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
     for (int i = 0; i < 8; i++) st1[i] = st2[i] = 0.f;
     int cur_n = -1;             // sample of the plane whose row phase is pending
     auto stat_flush = [&]() {
-        if (!HAS_STATS || cur_n < 0) return;
+        if (!(HAS_STATS || HAS_BST) || cur_n < 0) return;
         float* dst = a.stat_slab + ((((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * a.N + cur_n) * 32) * 2;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -179,11 +184,12 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
     float ev[8];                // residual variant: the row's values between convert and pack
     bf16* est = est_s + wave * (64 * EP);
     // bias of the channels this lane holds in the accumulator layout: 16 ct + 4 (lane >> 4) + i
+    // (the input-gradient role with backward sums has no bias, and no registers to spare for one)
     float bias4[2][4];
 #pragma unroll
     for (int ct = 0; ct < 2; ct++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) bias4[ct][i] = a.bias ? a.bias[co_b + 16 * ct + 4 * (lane >> 4) + i] : 0.f;
+        for (int i = 0; i < 4; i++) bias4[ct][i] = (!HAS_BST && a.bias) ? a.bias[co_b + 16 * ct + 4 * (lane >> 4) + i] : 0.f;
     // row phase: lane -> voxel lane >> 2 of the 16-run, channels 8 (lane & 3)..; byte offsets against a wave-uniform
     // row pointer
     const int yvoff = ((lane >> 2) * a.ldy + (lane & 3) * 8) * 2;
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
         constexpr int m = id >> 2, ct = (id >> 1) & 1;
         if constexpr ((id & 1) == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) bt[i] = acc[PARP][m][ct][i] + bias4[ct][i];
+            for (int i = 0; i < 4; i++) bt[i] = HAS_BST ? acc[PARP][m][ct][i] : acc[PARP][m][ct][i] + bias4[ct][i];
         } else {
             *reinterpret_cast<bf16x4*>(est + (m * 16 + (lane & 15)) * EP + 16 * ct + 4 * (lane >> 4)) =
                 __builtin_convertvector(bt, bf16x4);                                // two packed converts
@@ -214,13 +220,20 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
             rv = *reinterpret_cast<const bf16x8*>(est + (16 * p + (lane >> 2)) * EP + (lane & 3) * 8);
         } else if constexpr (k <= 8) {
             constexpr int i = k - 1;
-            if constexpr (HAS_STATS || HAS_RES) {
+            if constexpr (HAS_STATS || HAS_RES || HAS_BST) {
                 const float v = (float)rv[i];                                      // the stored value of conv + bias
                 if constexpr (HAS_STATS) {
                     st1[i] += v;
                     st2[i] = fmaf(v, v, st2[i]);
                 }
                 if constexpr (HAS_RES) ev[i] = v + (float)rq[p][i];
+                if constexpr (HAS_BST) {
+                    const float o = (float)rq[p][i];                               // the activation lrelu(xhat)
+                    const bool pos = o > 0.f;
+                    const float gp = v * (pos ? 1.f : a.slope);
+                    st1[i] += gp;
+                    st2[i] = fmaf(gp, o * (pos ? 1.f : a.inv_slope), st2[i]);
+                }
             }
         } else {
             char* dst = yprev + p * yrow_b + yvoff;
@@ -286,7 +299,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
         // this wave's output rows in plane d0
         ycur = reinterpret_cast<char*>(a.y + co_b) +
                ((((int64_t)n * a.D + d0) * a.H + h0 + RH * hr) * a.W + w0 + 16 * hw) * (int64_t)a.ldy * 2;
-        if constexpr (HAS_RES)
+        if constexpr (HAS_RES || HAS_BST)
             rcur = reinterpret_cast<const char*>(a.res + co_b) +
                    ((((int64_t)n * a.D + d0) * a.H + h0 + RH * hr) * a.W + w0 + 16 * hw) * (int64_t)a.ldr * 2;
         if (first) yprev = ycur;
@@ -340,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
                         else if constexpr (j % 3 == 1) {
                             constexpr int nn = (q - 3) * 4 + (j - 1) / 3;
                             if constexpr (nn < 20) micro_c(std::integral_constant<int, 20 + nn>{});
-                            else if constexpr (HAS_RES)
+                            else if constexpr (HAS_RES || HAS_BST)
                                 rq[nn - 20] = *reinterpret_cast<const bf16x8*>(rcur + (nn - 20) * rrow_b + rvoff);
                         }
                     }
@@ -351,7 +364,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
             SLIDE_STAMP_RT(PH, 121, s)
             yprev = ycur;
             ycur += yplane_b;
-            if constexpr (HAS_RES) rcur += rplane_b;
+            if constexpr (HAS_RES || HAS_BST) rcur += rplane_b;
         };
 
         // fragments of the first pass of step 0
@@ -364,7 +377,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
 #pragma unroll
                     for (int i = 0; i < 8; i++) st1[i] = st2[i] = 0.f;
                     first = false;
-                } else if (HAS_STATS && n != cur_n) {
+                } else if ((HAS_STATS || HAS_BST) && n != cur_n) {
                     stat_flush();
                 }
                 cur_n = n;
@@ -436,7 +449,7 @@ bool slide_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* o
 }
 
 int conv_slide_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
-                      float* stat_slab, hipStream_t st) {
+                      float* stat_slab, hipStream_t st, const void* bst_act, int bst_ld, float slope) {
     SlidePlan p;
     if (!slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &p))
         return ru3d_fail(-1, "conv_slide: shape not supported");
@@ -445,6 +458,7 @@ int conv_slide_launch(const void* x, const void* w, const float* bias, const voi
     if ((int64_t)g.Do * g.Ho * g.Wo * g.ldx >= (1ll << 30)) return ru3d_fail(-1, "conv_slide: sample too large");
     // residual + statistics together is not a combination any entry point produces (ru3d_conv3d_fwd_in has no residual)
     if (res && stat_slab) return ru3d_fail(-1, "conv_slide: residual and fused statistics cannot be combined");
+    if (bst_act && (res || !stat_slab)) return ru3d_fail(-1, "conv_slide: the backward sums need a slab and no residual");
     Slide32Args a;
     a.x = (const bf16*)x;
     a.w = (const bf16x8*)w;
@@ -456,12 +470,18 @@ int conv_slide_launch(const void* x, const void* w, const float* bias, const voi
     a.ldx = g.ldx; a.ldy = g.ldy; a.ldr = g.ldr;
     a.flip = g.flip;
     a.cout_total = g.Cout;
+    a.slope = slope;
+    a.inv_slope = slope != 0.f ? 1.f / slope : 0.f;
     a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w; a.dsplit = p.dsplit; a.DL = p.DL; a.units = p.units;
 #ifdef RU3D_SLIDE_STAMPS
     a.stamps = g_slide_stamps;
 #endif
     const dim3 grid(p.grid, p.ny), block(256);
-    if (res) hipLaunchKernelGGL((conv3_s1_slide32_kernel<true, false>), grid, block, 0, st, a);
+    if (bst_act) {
+        a.res = (const bf16*)bst_act;
+        a.ldr = bst_ld;
+        hipLaunchKernelGGL((conv3_s1_slide32_kernel<false, false, true>), grid, block, 0, st, a);
+    } else if (res) hipLaunchKernelGGL((conv3_s1_slide32_kernel<true, false>), grid, block, 0, st, a);
     else if (stat_slab) hipLaunchKernelGGL((conv3_s1_slide32_kernel<false, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((conv3_s1_slide32_kernel<false, false>), grid, block, 0, st, a);
     return ru3d_check_launch("conv3_s1_slide32");

@@ -11,6 +11,9 @@
     X(ru3d_conv3d_fwd_in_workspace_bytes) \
     X(ru3d_conv3d_fwd_in) \
     X(ru3d_conv3d_dgrad) \
+    X(ru3d_conv3d_dgrad_in_bwd_workspace_bytes) \
+    X(ru3d_conv3d_dgrad_in_bwd) \
+    X(ru3d_in_lrelu_bwd_apply) \
     X(ru3d_conv3d_wgrad_workspace_bytes) \
     X(ru3d_conv3d_wgrad) \
     X(ru3d_convtranspose3d_k3s2p1_fwd) \
@@ -37,6 +40,9 @@
 #define ru3d_conv3d_fwd_in_workspace_bytes ru3d_conv3d_fwd_in_workspace_bytes_f16
 #define ru3d_conv3d_fwd_in ru3d_conv3d_fwd_in_f16
 #define ru3d_conv3d_dgrad ru3d_conv3d_dgrad_f16
+#define ru3d_conv3d_dgrad_in_bwd_workspace_bytes ru3d_conv3d_dgrad_in_bwd_workspace_bytes_f16
+#define ru3d_conv3d_dgrad_in_bwd ru3d_conv3d_dgrad_in_bwd_f16
+#define ru3d_in_lrelu_bwd_apply ru3d_in_lrelu_bwd_apply_f16
 #define ru3d_conv3d_wgrad_workspace_bytes ru3d_conv3d_wgrad_workspace_bytes_f16
 #define ru3d_conv3d_wgrad ru3d_conv3d_wgrad_f16
 #define ru3d_convtranspose3d_k3s2p1_fwd ru3d_convtranspose3d_k3s2p1_fwd_f16

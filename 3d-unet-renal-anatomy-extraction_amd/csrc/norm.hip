@@ -584,6 +584,37 @@ extern "C" int ru3d_in_lrelu_bwd(const ru3d_tensor* gout, const ru3d_tensor* out
     return ru3d_fail(-1, "in_lrelu_bwd: bad dtype %d", dtype);
 }
 
+// the apply pass alone, with the two means given (ru3d_conv3d_dgrad_in_bwd: they come out of the conv's epilogue)
+template <typename T>
+static int in_bwd_apply_impl(const ru3d_tensor* gout, const ru3d_tensor* out, const float* mean, const float* scale,
+                             const float* m12, const ru3d_tensor* dy, float slope, int zero_far, hipStream_t st) {
+    const int64_t V = (int64_t)out->d * out->h * out->w;
+    const int vec = pick_vec<T>(out->c, {gout, out, dy});
+    ChanLoop ca = make_chanloop(V, out->c, vec, 16, out->n);
+    dim3 grida(ca.chunks, out->n, (ca.G + ca.Gb - 1) / ca.Gb);
+#define CALL(TT, VV)                                                                                                  \
+    hipLaunchKernelGGL((in_lrelu_bwd_kernel<TT, VV, false>), grida, dim3(256), 0, st, (const TT*)gout->ptr, gout->ld, \
+                       (const TT*)out->ptr, out->ld, (const TT*)out->ptr, out->ld, mean, scale, m12, (TT*)dy->ptr,    \
+                       dy->ld, (TT*)0, 0, slope, zero_far, out->d, out->h, out->w, ca, out->c)
+    DISPATCH_VEC(T, vec, CALL)
+#undef CALL
+    return ru3d_check_launch("in_lrelu_bwd_apply");
+}
+
+extern "C" int ru3d_in_lrelu_bwd_apply(const ru3d_tensor* gout, const ru3d_tensor* out, const float* mean,
+                                       const float* scale, const float* m12, const ru3d_tensor* dy, float slope,
+                                       int zero_far, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_in_lrelu_bwd_apply_f16(gout, out, mean, scale, m12, dy, slope, zero_far, dtype, stream));
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(tensor_ok(gout) && tensor_ok(out) && tensor_ok(dy), "in_lrelu_bwd_apply: bad tensor");
+    RU3D_REQUIRE(same_shape(out, gout) && same_shape(out, dy), "in_lrelu_bwd_apply: shape mismatch");
+    RU3D_REQUIRE(mean && scale && m12, "in_lrelu_bwd_apply: null stats");
+    RU3D_REQUIRE((int64_t)out->d * out->h * out->w < (1ll << 31), "in_lrelu_bwd_apply: sample too large");
+    if (dtype == RU3D_F32) return in_bwd_apply_impl<float>(gout, out, mean, scale, m12, dy, slope, zero_far, as_stream(stream));
+    if (dtype == RU3D_BF16) return in_bwd_apply_impl<bf16>(gout, out, mean, scale, m12, dy, slope, zero_far, as_stream(stream));
+    return ru3d_fail(-1, "in_lrelu_bwd_apply: bad dtype %d", dtype);
+}
+
 template <typename T>
 static int chansum_impl(const ru3d_tensor* t, float* out, void* ws, hipStream_t st) {
     const int64_t V = (int64_t)t->d * t->h * t->w;

@@ -280,6 +280,22 @@ int ru3d_adam_multi(const ru3d_adam_tensor* tensors, const int32_t* block_map, i
 int ru3d_adam_multi_dev(const ru3d_adam_tensor* tensors, const int32_t* block_map, int nblocks, int chunk_elems,
                         const float* hyper, void* stream);
 
+/* conv3d input gradient FOLLOWED by the InstanceNorm + LeakyReLU backward of the tensor it differentiates (ResBlock
+ * backward, network.py:411-416 read backwards: da = conv2^T(dy); dyn = d/dy1 of lrelu(IN(y1)) given da) - the
+ * mirror image of ru3d_conv3d_fwd_in.  `act` = lrelu(IN(y1)) as the forward produced it, mean / scale = that
+ * InstanceNorm's statistics; da receives the conv's result (gradient wrt act), dyn the gradient wrt y1.  On the
+ * shapes of the sliding 32-channel kernel the two sums the backward needs (sum g', sum g' xhat) are taken in the
+ * conv's epilogue and the separate reduction pass over (da, act) is not run; elsewhere the call is
+ * ru3d_conv3d_dgrad + ru3d_in_lrelu_bwd.  Workspace: ru3d_conv3d_dgrad_in_bwd_workspace_bytes. */
+size_t ru3d_conv3d_dgrad_in_bwd_workspace_bytes(const ru3d_tensor* dy, const ru3d_tensor* da, int k, int stride,
+                                                int dtype);
+int ru3d_conv3d_dgrad_in_bwd(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* act, const float* mean,
+                             const float* scale, const ru3d_tensor* da, const ru3d_tensor* dyn, int k, int stride,
+                             float slope, int dtype, void* ws, size_t ws_bytes, void* stream);
+/* The apply pass of ru3d_in_lrelu_bwd alone (no residual form), with m12[n][c] = (mean g', mean g' xhat) given. */
+int ru3d_in_lrelu_bwd_apply(const ru3d_tensor* gout, const ru3d_tensor* out, const float* mean, const float* scale,
+                            const float* m12, const ru3d_tensor* dy, float slope, int zero_far, int dtype, void* stream);
+
 /* Dynamic loss scaling of the fp16 mode (the reference's apex O1: trainer.py:492-493 amp.scale_loss, 538-542
  * amp.initialize): every gradient named by the table (same layout as ru3d_adam_multi; only grad / count are read) is
  * checked for inf / nan - *found_inf is set to 1.0 when one is found; the caller zeroes it beforehand - and multiplied

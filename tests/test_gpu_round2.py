@@ -227,3 +227,29 @@ def test_mfma_packed_weight_is_not_handed_to_the_direct_kernel():
         ops.conv_fwd(x, pw, None, 32, 3, 1, out_dtype=torch.float32)
     y = ops.conv_fwd(x, pw, None, 32, 3, 1)                        # the supported combination still runs
     assert y.dtype == torch.bfloat16 and torch.isfinite(y).all()
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 16, 32, 64), (1, 32, 8, 8, 32), (2, 64, 8, 16, 32), (1, 16, 6, 10, 12)])
+def test_conv_dgrad_in_bwd_fused_equals_two_calls(shape):
+    """ru3d_conv3d_dgrad_in_bwd (the IN + LeakyReLU backward sums taken in the epilogue of the sliding 32-channel conv)
+    against ru3d_conv3d_dgrad followed by ru3d_in_lrelu_bwd: same da up to the rounding of the sums (fp32 partials per
+    wave instead of double partials per block), and the plain two-call path on shapes the fused form does not take."""
+    n, c, d, h, w = shape
+    torch.manual_seed(5)
+    dt = torch.bfloat16
+    y1 = ops.as_input(torch.randn(n, c, d, h, w, device=DEV) * 2 + 0.3, dt)
+    mean, scale = ops.in_stats(y1)
+    a1 = ops.in_lrelu_fwd(y1, mean, scale)
+    dy2 = ops.as_input(torch.randn(n, c, d, h, w, device=DEV), dt)
+    wt = torch.randn(c, c, 3, 3, 3, device=DEV) * (1.0 / (27 * c) ** 0.5)
+    pwd = ops.pack_weight(wt, N.ROLE_CONV_DGRAD, dt, 1)
+    da = ops.conv_dgrad(dy2, pwd, tuple(a1.shape), 3, 1)
+    ref, _ = ops.in_lrelu_bwd(da, a1, y1, mean, scale)
+    got = ops.conv_dgrad_in_bwd(dy2, pwd, a1, mean, scale)
+    torch.cuda.synchronize()
+    r, g = ref.float(), got.float()
+    assert torch.isfinite(g).all()
+    err = (g - r).abs().max().item()
+    assert err <= 2e-2 * r.abs().max().item() + 1e-3, (err, r.abs().max().item())
+    # the bulk is bit-equal: only elements whose value sits on a bf16 rounding boundary may move by one ulp
+    assert (g != r).float().mean().item() < 0.02
