@@ -225,27 +225,28 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const double* __res
     scale[i] = (float)(s / sqrt(s * s * var + (double)eps));
 }
 
-// backward finalize: m1 = mean(gpre), m2 = mean(gpre * xhat), stored right after the partials
-__global__ __launch_bounds__(256) void bwd_finalize_kernel(const double* __restrict__ part, int chunks, int C, int NC,
-                                                           double invV, float* __restrict__ m12) {
-    const int i = blockIdx.x * FIN_CX + threadIdx.x % FIN_CX;
-    const bool ok = i < NC;
-    const int n = ok ? i / C : 0, c = ok ? i % C : 0;
-    double t1, t2;
-    finalize_sums(part + (int64_t)n * chunks * C * 2, chunks, (int64_t)C * 2, c, ok, t1, t2);
-    if (!ok || threadIdx.x >= FIN_CX) return;
-    m12[2 * i] = (float)(t1 * invV);
-    m12[2 * i + 1] = (float)(t2 * invV);
-}
-
-// sum over n and voxels of gpre from the per-sample means m1 = mean_v(gpre): out[c] = V * sum_n m1[n][c]
-__global__ __launch_bounds__(256) void gpre_sum_kernel(const float* __restrict__ m12, int N, int C, double V,
-                                                       float* __restrict__ out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+// backward finalize: m1 = mean(gpre), m2 = mean(gpre * xhat), stored right after the partials.  A block takes FIN_CX
+// channels and walks the samples, so the skip conv's bias gradient - sum over n and voxels of gpre = V * sum_n m1[n][c],
+// formed from the rounded m1 like the separate pass it replaces - comes out of the same launch.
+__global__ __launch_bounds__(256) void bwd_finalize_kernel(const double* __restrict__ part, int chunks, int C, int N,
+                                                           double invV, float* __restrict__ m12, double V,
+                                                           float* __restrict__ gpre_sum) {
+    const int c = blockIdx.x * FIN_CX + threadIdx.x % FIN_CX;
+    const bool ok = c < C;
     double s = 0.0;
-    for (int n = 0; n < N; n++) s += (double)m12[2 * (n * C + c)];
-    out[c] = (float)(s * V);
+    for (int n = 0; n < N; n++) {
+        double t1, t2;
+        finalize_sums(part + (int64_t)n * chunks * C * 2, chunks, (int64_t)C * 2, ok ? c : 0, ok, t1, t2);
+        if (ok && threadIdx.x < FIN_CX) {
+            const int i = n * C + c;
+            const float m1 = (float)(t1 * invV);
+            m12[2 * i] = m1;
+            m12[2 * i + 1] = (float)(t2 * invV);
+            s += (double)m1;
+        }
+        __syncthreads();   // finalize_sums' shared partials are reused by the next sample
+    }
+    if (gpre_sum && ok && threadIdx.x < FIN_CX) gpre_sum[c] = (float)(s * V);
 }
 
 __global__ __launch_bounds__(256) void chansum_finalize_kernel(const double* __restrict__ part, int chunks, int C,
@@ -521,7 +522,6 @@ static int in_bwd_impl(const ru3d_tensor* gout, const ru3d_tensor* out, const ru
     ChanLoop cl = make_chanloop(V, y->c, vec, 64, y->n);
     dim3 grid(cl.chunks, y->n, (cl.G + cl.Gb - 1) / cl.Gb);
     double* part = (double*)ws;
-    const int NC = y->n * y->c;
     float* m12 = (float*)((char*)ws + (size_t)y->n * cl.chunks * y->c * 2 * sizeof(double));
 #define CALL(TT, VV)                                                                                                  \
     if (gpre)                                                                                                         \
@@ -535,16 +535,10 @@ static int in_bwd_impl(const ru3d_tensor* gout, const ru3d_tensor* out, const ru
 #undef CALL
     int rc = ru3d_check_launch("in_lrelu_bwd_reduce");
     if (rc) return rc;
-    hipLaunchKernelGGL(bwd_finalize_kernel, dim3((NC + FIN_CX - 1) / FIN_CX), dim3(256), 0, st, (const double*)part, cl.chunks,
-                       y->c, NC, 1.0 / (double)V, m12);
+    hipLaunchKernelGGL(bwd_finalize_kernel, dim3((y->c + FIN_CX - 1) / FIN_CX), dim3(256), 0, st, (const double*)part,
+                       cl.chunks, y->c, y->n, 1.0 / (double)V, m12, (double)V, gpre_sum);
     rc = ru3d_check_launch("in_lrelu_bwd_finalize");
     if (rc) return rc;
-    if (gpre_sum) {
-        hipLaunchKernelGGL(gpre_sum_kernel, dim3((y->c + 255) / 256), dim3(256), 0, st, (const float*)m12, y->n, y->c,
-                           (double)V, gpre_sum);
-        rc = ru3d_check_launch("in_lrelu_bwd_gpre_sum");
-        if (rc) return rc;
-    }
     ChanLoop ca = make_chanloop(V, y->c, vec, 16, y->n);
     dim3 grida(ca.chunks, y->n, (ca.G + ca.Gb - 1) / ca.Gb);
 #define CALL(TT, VV)                                                                                                  \
