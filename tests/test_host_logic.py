@@ -296,3 +296,35 @@ def test_stream_follows_the_operands_device(monkeypatch):
     N.note_device(torch.device("cuda", 0))
     N.stream()
     assert seen[-1] == torch.device("cuda", 0)
+
+
+def test_adam_capture_scalars_follow_step_counts_and_lr():
+    """optim.Adam's captured-step interface (graph.GraphedTrainStep): the scalars uploaded before replay k are those of
+    eager step k - bias corrections from the advancing step count, the current lr, sqrt(bias_corr2) as the eager launch
+    takes it - and the counts flow back into state_dict()."""
+    import math
+    import optim
+    p = torch.nn.Parameter(torch.zeros(4))
+    opt = optim.Adam([p], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+    with pytest.raises(ValueError):
+        opt.begin_capture(torch.zeros(2, 8))                 # one row per param group
+    opt._captured = {"hyper": None, "steps": {0: 3.0}}       # as the capture of step 4 leaves it
+    opt.state[p] = {"step": torch.tensor(4.0), "exp_avg": torch.zeros(4), "exp_avg_sq": torch.zeros(4)}
+    row = torch.zeros(1, 8)
+    opt.replay_scalars(row)                                  # first replay = step 4
+    assert opt._captured["steps"][0] == 4.0
+    exp = [1e-3, 0.9, 0.999, 1e-8, 1 - 0.9 ** 4, 1 - 0.999 ** 4, 1.0]
+    assert torch.allclose(row[0, :7], torch.tensor(exp, dtype=torch.float32), rtol=1e-6, atol=0)
+    assert abs(float(row[0, 7]) - math.sqrt(float(row[0, 5]))) < 1e-7
+    opt.param_groups[0]["lr"] = 5e-4                         # a scheduler between replays
+    opt.replay_scalars(row, grad_scale=0.5)
+    assert float(row[0, 0]) == pytest.approx(5e-4) and float(row[0, 6]) == 0.5
+    assert float(row[0, 4]) == pytest.approx(1 - 0.9 ** 5, rel=1e-6)
+    assert float(opt.state_dict()["state"][0]["step"]) == 5.0
+
+
+def test_graphed_step_needs_the_fused_optimizer():
+    import graph
+    m = torch.nn.Linear(2, 2)
+    with pytest.raises(TypeError):
+        graph.GraphedTrainStep(m, torch.nn.MSELoss(), torch.optim.Adam(m.parameters()))
