@@ -418,7 +418,10 @@ def test_conv_with_channel_pitch_and_odd_extents(dtype):
                                    (1, 128, 64, 5, 5, 7), (1, 32, 96, 2, 3, 33), (1, 32, 32, 8, 8, 8),
                                    (2, 32, 32, 64, 64, 64), (1, 32, 32, 24, 64, 96), (5, 32, 32, 4, 128, 128),
                                    (2, 32, 64, 32, 64, 64), (2, 64, 64, 64, 64, 64), (1, 64, 64, 8, 8, 32),
-                                   (3, 64, 128, 12, 16, 64), (2, 64, 32, 32, 32, 64), (1, 64, 32, 8, 8, 32)])
+                                   (3, 64, 128, 12, 16, 64), (2, 64, 32, 32, 32, 64), (1, 64, 32, 8, 8, 32),
+                                   # more columns than workgroups: a workgroup finishes one column's last plane inside the
+                                   # next column's first step, across a change of sample
+                                   (6, 32, 32, 16, 64, 128), (5, 32, 64, 8, 64, 128)])
 def test_mfma_conv_s1_bf16(shape):
     """The bf16 MFMA implicit-GEMM kernel (3x3x3, stride 1) on ragged extents, with bias + residual, as a
     forward conv and as the tap-reversed input gradient, and the wgrad of the same shapes.  Reference:
@@ -529,7 +532,7 @@ def test_mfma_convtranspose_bf16(cin, cout, dims):
 @pytest.mark.parametrize("shape", [(2, 32, 32, 40, 36, 64), (1, 64, 64, 33, 40, 48), (3, 32, 64, 24, 24, 24),
                                    (1, 32, 32, 6, 6, 8), (2, 32, 32, 64, 64, 64), (5, 32, 32, 4, 128, 128),
                                    (3, 32, 32, 16, 64, 64), (2, 32, 64, 32, 64, 64), (2, 64, 64, 64, 64, 64),
-                                   (3, 64, 128, 12, 16, 64), (2, 64, 32, 32, 32, 64)])
+                                   (3, 64, 128, 12, 16, 64), (2, 64, 32, 32, 32, 64), (6, 32, 32, 16, 64, 128)])
 def test_conv_fwd_in_fused_statistics(shape):
     """ru3d_conv3d_fwd_in: conv + InstanceNorm statistics.  On the persistent producer/consumer MFMA kernel the
     sums come from the conv epilogue; they must agree with a separate statistics pass over the stored output

@@ -229,7 +229,8 @@ def test_mfma_packed_weight_is_not_handed_to_the_direct_kernel():
     assert y.dtype == torch.bfloat16 and torch.isfinite(y).all()
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 16, 32, 64), (1, 32, 8, 8, 32), (2, 64, 8, 16, 32), (1, 16, 6, 10, 12)])
+@pytest.mark.parametrize("shape", [(2, 32, 16, 32, 64), (1, 32, 8, 8, 32), (2, 64, 8, 16, 32), (1, 16, 6, 10, 12),
+                                   (6, 32, 16, 64, 128)])     # columns > workgroups, samples change inside a workgroup
 def test_conv_dgrad_in_bwd_fused_equals_two_calls(shape):
     """ru3d_conv3d_dgrad_in_bwd (the IN + LeakyReLU backward sums taken in the epilogue of the sliding 32-channel conv)
     against ru3d_conv3d_dgrad followed by ru3d_in_lrelu_bwd: same da up to the rounding of the sums (fp32 partials per
