@@ -173,10 +173,20 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
             fetch(std::integral_constant<int, 1>{}, 1);
             static_for<0, 16>([&](auto ksc) {
                 constexpr int ks = decltype(ksc)::value;
-                if constexpr (ks + 2 < 16) fetch(std::integral_constant<int, ks + 2>{}, (ks + 2) % 3);
-#pragma unroll
-                for (int t = 0; t < 7; t++)
+                // the fragments of k-step ks + 2 are read one tap behind each MFMA (two transposed LDS reads fit in an
+                // MFMA's shadow; all 16 in front of the seven MFMAs held the issue port while the matrix pipe drained)
+                constexpr int rowb2 = (((ks + 2) & 15) >> 1) * WW + (((ks + 2) & 15) & 1) * 16;
+                static_for<0, 7>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
                     acc[t] = RU3D_MFMA_32X32X16(aq[ks % 3][t], bq[ks % 3], acc[t], 0, 0, 0);
+                    if constexpr (ks + 2 < 16) {
+                        if constexpr (t == 0) bq[(ks + 2) % 3] = tr_frag(db + ((ks + 2) * 16 + 8 * h) * 32 + lane_off);
+                        const int tap = wave + 4 * t < 27 ? wave + 4 * t : 26;
+                        const int slot = (PH + tap / 9) & 3;
+                        aq[(ks + 2) % 3][t] = tr_frag(lds + slot * XPLANE + (rowb2 + 8 * h) * 32 + toff[t] + lane_off);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
                 // Staging, one 16-byte piece behind each k-step's MFMAs (as one block at the top of the step it idled the
                 // matrix pipe for its ~120 instructions): the X plane / DY rows loaded during the previous step go to the
                 // ring slot and DY buffer that died with it, and the freed registers take the same piece of the next
