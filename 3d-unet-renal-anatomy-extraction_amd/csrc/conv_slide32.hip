@@ -412,6 +412,9 @@ extern "C" void ru3d_debug_slide_stamps(long long* dev_buf) { g_slide_stamps = d
 bool slide_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* out) {
     static const int mode = getenv("RU3D_CONV_SLIDE") ? atoi(getenv("RU3D_CONV_SLIDE")) : 1;
     if (mode == 0 || Cin != 32 || (Cout != 32 && Cout != 64) || (H % TH) || (W % TW) || D < 4) return false;
+    // the staging loads address a sample with 30-bit element offsets; the input may sit in a buffer of twice its channels
+    // (the decoder's concat): shapes that could exceed that go to the other kernels consistently (launch, slab, workspace)
+    if ((int64_t)D * H * W * Cin * 2 >= (1ll << 30)) return false;
     const int ny = Cout / 32;
     const int64_t cols = (int64_t)N * (H / TH) * (W / TW);
     int64_t best_cost = -1;

@@ -362,6 +362,9 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
 bool slide64_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* out) {
     static const int mode = getenv("RU3D_CONV_SLIDE64") ? atoi(getenv("RU3D_CONV_SLIDE64")) : 1;
     if (mode == 0 || Cin != 64 || (Cout != 32 && Cout != 64 && Cout != 128) || (H % TH) || (W % TW) || D < 4) return false;
+    // the staging loads address a sample with 30-bit element offsets; the input may sit in a buffer of twice its channels
+    // (the decoder's concat): shapes that could exceed that go to the other kernels consistently (launch, slab, workspace)
+    if ((int64_t)D * H * W * Cin * 2 >= (1ll << 30)) return false;
     const int ny = Cout == 32 ? 1 : Cout / 64;
     const int64_t cols = (int64_t)N * (H / TH) * (W / TW);
     int64_t best_cost = -1;
