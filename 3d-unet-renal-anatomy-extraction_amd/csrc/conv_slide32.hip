@@ -93,12 +93,13 @@ __device__ __forceinline__ void mfma16(f32x4& acc, const bf16x8& w, const bf16x8
 // issue port for 8 of its 16 cycles: two single-issue instructions fit behind every MFMA for free, a clump of thirty
 // between two MFMAs idles the matrix pipe for its whole length.  So everything that is not an MFMA is cut into
 // micro-operations of three or four instructions and pinned (sched_barrier) behind a fixed MFMA pair of the step:
-//   passes 0-2 (36 pairs): the previous plane's 8 accumulator tiles -> bias, rounding, wave-private LDS patch (2 micro-ops
-//     per tile), then the row phase of output rows 0 and 1 (10 micro-ops each: patch read, 8 x one channel's
-//     convert / statistics / residual, pack + 16-byte store);
+//   the previous plane's epilogue, output row by output row, on the pairs that carry no staging: the row's 2 accumulator
+//     tiles -> bias, rounding, wave-private LDS patch (4 micro-ops per tile: two adds, two adds, two converts, the
+//     write), then its row phase (10 micro-ops: patch read, 8 x one channel's convert / statistics / residual, pack +
+//     16-byte store) - 72 micro-ops on the first 72 of the 96 free pairs;
 //   passes 3-8: LDS-only barrier in front of pass 3; per pass one 16-byte piece of plane s+3 to LDS (pair 3), the same
-//     piece of plane s+4 from HBM into the freed registers (pair 6), row phase of output rows 2 and 3 on pairs 1, 4, 7,
-//     10; in pass 8 those four pairs issue the residual loads of the plane being computed;
+//     piece of plane s+4 from HBM into the freed registers (pair 6); in pass 8 pairs 1, 4, 7, 10 also issue the residual
+//     loads of the plane being computed;
 //   behind the last pair of every input row: that row's fragment for the next pass.
 // The previous plane's epilogue always runs - at the first step of a column it finishes the last plane of the PREVIOUS
 // column (pointers and accumulators carry over), so there is no per-step condition and no separate tail except once at
@@ -180,7 +181,8 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
     bf16x8 stg[NSTG];           // the plane in flight from HBM to LDS
     bf16x8 rq[4];               // residual rows of the plane being computed (consumed by the next step)
     bf16x8 rv;                  // patch row of the row phase
-    f32x4 bt;                   // accumulator tile + bias between its two micro-ops
+    f32x4 bt;                   // accumulator tile + bias between its micro-ops
+    bf16x4 btp;                 // ... rounded
     float ev[8];                // residual variant: the row's values between convert and pack
     bf16* est = est_s + wave * (64 * EP);
     // bias of the channels this lane holds in the accumulator layout: 16 ct + 4 (lane >> 4) + i
@@ -202,15 +204,16 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
     bool first = true;
 
     // ---- micro-operations of the epilogue of the plane in acc[PARP] -------------------------------------------------
-    auto micro_b = [&](auto parp, auto idc) {            // id = 0..15: tile id >> 1 = (m, ct), half id & 1
+    auto micro_b = [&](auto parp, auto idc) {            // id = 0..31: tile id >> 2 = (m, ct), quarter id & 3
         constexpr int PARP = decltype(parp)::value, id = decltype(idc)::value;
-        constexpr int m = id >> 2, ct = (id >> 1) & 1;
-        if constexpr ((id & 1) == 0) {
+        constexpr int m = id >> 3, ct = (id >> 2) & 1, qt = id & 3;
+        if constexpr (qt < 2) {                              // two bias adds
 #pragma unroll
-            for (int i = 0; i < 4; i++) bt[i] = HAS_BST ? acc[PARP][m][ct][i] : acc[PARP][m][ct][i] + bias4[ct][i];
+            for (int i = 2 * qt; i < 2 * qt + 2; i++) bt[i] = HAS_BST ? acc[PARP][m][ct][i] : acc[PARP][m][ct][i] + bias4[ct][i];
+        } else if constexpr (qt == 2) {                      // two packed converts
+            btp = __builtin_convertvector(bt, bf16x4);
         } else {
-            *reinterpret_cast<bf16x4*>(est + (m * 16 + (lane & 15)) * EP + 16 * ct + 4 * (lane >> 4)) =
-                __builtin_convertvector(bt, bf16x4);                                // two packed converts
+            *reinterpret_cast<bf16x4*>(est + (m * 16 + (lane & 15)) * EP + 16 * ct + 4 * (lane >> 4)) = btp;
         }
     };
     auto micro_c = [&](auto cidc) {                      // cid = 10 p + k: output row p, k = 0 read, 1..8 channel, 9 store
@@ -343,19 +346,20 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
                         else frag_row(std::integral_constant<int, (PH + 1) & 3>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, r>{});
                     }
                     // the micro-operation pinned behind this pair
-                    if constexpr (q < 3) {
-                        constexpr int id = q * NJ + j;
-                        if constexpr (id < 16) micro_b(std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<int, id>{});
-                        else micro_c(std::integral_constant<int, id - 16>{});
+                    constexpr bool staging = q >= 3 && (j == 3 || j == 6);
+                    if constexpr (staging) {
+                        if constexpr (j == 3) store_piece((PH + 3) & 3, std::integral_constant<int, (q >= 3 ? q - 3 : 0)>{});
+                        else load_piece(s + 4, std::integral_constant<int, (q >= 3 ? q - 3 : 0)>{});
                     } else {
-                        if constexpr (j == 3) store_piece((PH + 3) & 3, std::integral_constant<int, q - 3>{});
-                        else if constexpr (j == 6) load_piece(s + 4, std::integral_constant<int, q - 3>{});
-                        else if constexpr (j % 3 == 1) {
-                            constexpr int nn = (q - 3) * 4 + (j - 1) / 3;
-                            if constexpr (nn < 20) micro_c(std::integral_constant<int, 20 + nn>{});
-                            else if constexpr (HAS_RES || HAS_BST)
-                                rq[nn - 20] = *reinterpret_cast<const bf16x8*>(rcur + (nn - 20) * rrow_b + rvoff);
+                        // u-th pair without staging: 18 micro-ops per output row (8 tile quarters, 10 row phase)
+                        constexpr int u = q < 3 ? q * NJ + j : 36 + (q - 3) * 10 + j - (j > 3) - (j > 6);
+                        if constexpr (u < 72) {
+                            constexpr int p = u / 18, w = u % 18;
+                            if constexpr (w < 8) micro_b(std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<int, 8 * p + w>{});
+                            else micro_c(std::integral_constant<int, 10 * p + w - 8>{});
                         }
+                        if constexpr ((HAS_RES || HAS_BST) && q == NP - 1 && j % 3 == 1)
+                            rq[(j - 1) / 3] = *reinterpret_cast<const bf16x8*>(rcur + ((j - 1) / 3) * rrow_b + rvoff);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
     // the workgroup's last plane (parity 1: DL is a multiple of 4) has no next step to hide behind
     if (!first) {
         asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[1][3][0]), "+v"(acc[1][3][1]));
-        static_for<0, 16>([&](auto idc) { micro_b(std::integral_constant<int, 1>{}, idc); });
+        static_for<0, 32>([&](auto idc) { micro_b(std::integral_constant<int, 1>{}, idc); });
         static_for<0, 40>([&](auto cidc) { micro_c(cidc); });
     }
     stat_flush();
