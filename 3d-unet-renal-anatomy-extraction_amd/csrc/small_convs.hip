@@ -63,13 +63,14 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const T* __restrict__ x, 
 // input patch goes to LDS, every thread expands ONE position into its 32-tap row (im2col in LDS, 80-byte rows), each
 // wave runs 4 MFMAs for its two 32-position rows and writes them through a wave-private patch as 16-byte NDHWC
 // stores.  The VALU form above issues 27 two-byte loads per thread; this one is bound by the 2F bytes it writes.
-#define STEM_FWD_BLOCKS 1024
+#define STEM_FWD_BLOCKS 1792   /* 7 workgroups of 22.5 KB LDS per CU: the tile loop is a chain of barriers, residency hides it */
 __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
                                                             const float* __restrict__ bias, bf16* __restrict__ y,
                                                             ConvGeom g, int tiles_h, int tiles_w, int ntiles) {
     __shared__ __attribute__((aligned(16))) bf16 xs[3 * 10 * 34 + 4];
-    __shared__ __attribute__((aligned(16))) bf16 pm[256 * 40];         // im2col rows: 32 taps + pad
-    __shared__ __attribute__((aligned(16))) bf16 est[4 * 64 * 40];     // epilogue patches
+    // im2col rows: 32 taps + pad.  A wave's 64 rows double as its epilogue patch (same pitch; a row is rewritten only
+    // behind the MFMAs that read it, and only by the wave that owns it)
+    __shared__ __attribute__((aligned(16))) bf16 pm[256 * 40];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int co0 = blockIdx.y * 32;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const bf16* __restri
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         bq[q] = bias ? *reinterpret_cast<const f32x4*>(bias + co0 + 8 * q + 4 * h) : z4;
     }
-    bf16* patch = est + wave * (64 * 40);
+    bf16* patch = pm + wave * (64 * 40);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int t = tile;
