@@ -167,13 +167,161 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s2_tile_kernel(WS2Args a) {
     }
 }
 
-// two cout tiles per workgroup would halve the staging per output, but 14 accumulators + 26 staging pieces spill (718
-// VGPRs over budget); the sibling workgroup of the other cout tile reads the same rows through L2 instead
-static int s2_nco(const WgradGeom&) { return 1; }
+// ---------------------------------------------------------------------------------------------------------------
+// The same weight gradient with LDS-DMA staging.  The kernel above runs at the rate its CU takes bytes in: 104 KB of
+// gathered input per 128 positions and per (ci, co) tile pair - 852 MB for the 32 -> 64 conv at 128^3 where 335 MB are
+// needed - and cannot serve two cout tiles from one staging because 14 accumulators + 26 staging pieces do not fit the
+// register file.  Here the tile is half as wide (2 x 2 x 16 positions, 5 x 5 lines of 33 rows = 52 KB), double-buffered
+// in LDS, and filled by `buffer_load_dwordx4 ... lds`: a wave-instruction moves 64 x 16 bytes from 64 per-lane source
+// addresses into 1 KB of consecutive LDS, so the de-interleaved row order is just the order of the slots, rows outside
+// the volume come back as zeros (offset beyond the descriptor's range) and NO staging register exists - which makes
+// room for NCO = 2 (half the staging per output) with the 14 accumulators where the compiler puts them.
+constexpr int DW = 16;                                  // W extent of the output tile
+constexpr int DLW = 2 * DW + 1, DNE = DW + 1;           // 33 gathered rows per line: 17 even entries, 16 odd
+constexpr int DXROWS = LD * LH * DLW;                   // 825
+constexpr int DNPOS = TDO * THO * DW;                   // 64 positions
+constexpr int DXINSTR = (DXROWS * 4 + 63) / 64;         // 52 wave-instructions fill the input tile
+constexpr int DXI = (DXINSTR + 3) / 4;                  // 13 per wave
+constexpr int DXBUF = DXINSTR * 64 * 8;                 // elements per input buffer (53,248 B incl. the tail slots)
+static_assert(2 * (DXBUF + 2 * DNPOS * 32) * 2 <= 160 * 1024, "LDS budget");
+
+template <int NCO>
+__global__ __launch_bounds__(256, 1) void wgrad3_s2_dma_kernel(WS2Args a) {
+    __shared__ __attribute__((aligned(16))) bf16 lds[2 * (DXBUF + NCO * DNPOS * 32)];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int COT = a.Cout / (32 * NCO);
+    const int cit = blockIdx.y / COT, cot = (blockIdx.y % COT) * NCO;
+
+    int toff[7];
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        const int tap = wave + 4 * t < 27 ? wave + 4 * t : 26;
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        toff[t] = ((kd * LH + kh) * DLW + (kw == 1 ? DNE : (kw >> 1))) * 32;
+    }
+    f32x16 acc[7][NCO];
+#pragma unroll
+    for (int t = 0; t < 7; t++)
+#pragma unroll
+        for (int o = 0; o < NCO; o++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[t][o][i] = 0.f;
+    const int h = lane >> 5, cg = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = lane & 3;
+    const int lane_off = q * 32 + 16 * cg + 4 * p4;
+
+    // slot k = (wave + 4 i) * 64 + lane of the input tile: LDS row k >> 2 (line, then the even entries, then the odd
+    // ones), 16-byte piece k & 3.  Tile-invariant: byte offset against the tile's first gathered row, and the row's
+    // (d, h, w) position inside the tile for the bounds test of border tiles
+    int rel[DXI], zz[DXI];
+#pragma unroll
+    for (int i = 0; i < DXI; i++) {
+        const int k = (wave + 4 * i) * 64 + lane;
+        const int r = k >> 2, line = r / DLW, within = r - line * DLW;
+        const int e = within < DNE ? 2 * within : 2 * (within - DNE) + 1;
+        const int dz = line / LH, dh = line - dz * LH;
+        const bool slot_ok = wave + 4 * i < DXINSTR && r < DXROWS;
+        rel[i] = (((dz * a.Hi + dh) * a.Wi + e) * a.ldx + (k & 3) * 8) * 2;
+        zz[i] = slot_ok ? (dz | (dh << 8) | (e << 16)) : -1;
+    }
+    const int xsample_b = a.Di * a.Hi * a.Wi * a.ldx * 2, dsample_b = a.Do * a.Ho * a.Wo * a.lddy * 2;
+
+    auto issue_tile = [&](int tile, int buf) {
+        int tt = tile;
+        const int ow0 = (tt % a.tiles_w) * DW;
+        tt /= a.tiles_w;
+        const int oh0 = (tt % a.tiles_h) * THO;
+        tt /= a.tiles_h;
+        const int od0 = (tt % a.tiles_d) * TDO;
+        const int n = tt / a.tiles_d;
+        const int id0 = 2 * od0 - 1, ih0 = 2 * oh0 - 1, iw0 = 2 * ow0 - 1;
+        const bool interior = id0 >= 0 && id0 + LD <= a.Di && ih0 >= 0 && ih0 + LH <= a.Hi && iw0 >= 0 && iw0 + DLW <= a.Wi;
+        const int org = (((id0 * a.Hi + ih0) * a.Wi + iw0) * a.ldx + cit * 32) * 2;   // may be negative on a border tile
+        __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)n * (xsample_b / 2)), (short)0,
+                                                                      xsample_b, 0x00020000);
+        bf16* xb = lds + buf * (DXBUF + NCO * DNPOS * 32);
+#pragma unroll
+        for (int i = 0; i < DXI; i++) {
+            if (wave + 4 * i < DXINSTR) {                                            // wave-uniform
+                bool ok = zz[i] >= 0;
+                if (!interior) {
+                    const int id = id0 + (zz[i] & 255), ih = ih0 + ((zz[i] >> 8) & 255), iw = iw0 + ((zz[i] >> 16) & 255);
+                    ok = ok && id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+                }
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xb + (wave + 4 * i) * 512),
+                                                         16, ok ? org + rel[i] : (int)0x80000000, 0, 0, 0);
+            }
+        }
+        // DY rows: instruction j = wave + 4 o of NCO * 4: cout tile o, positions 16 wave + (lane >> 2), piece lane & 3
+        __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (int64_t)n * (dsample_b / 2)), (short)0,
+                                                                      dsample_b, 0x00020000);
+        const int pos = 16 * wave + (lane >> 2);
+        const int od = od0 + (pos >> 5), oh = oh0 + ((pos >> 4) & 1), ow = ow0 + (pos & 15);
+        const int doff = (((od * a.Ho + oh) * a.Wo + ow) * a.lddy + cot * 32 + (lane & 3) * 8) * 2;
+        bf16* db = xb + DXBUF;
+#pragma unroll
+        for (int o = 0; o < NCO; o++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (__attribute__((address_space(3))) void*)(db + o * (DNPOS * 32) + wave * 512),
+                                                     16, doff + o * 64, 0, 0, 0);
+    };
+
+    if ((int)blockIdx.x < a.ntiles) issue_tile(blockIdx.x, 0);
+    int buf = 0;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += a.G, buf ^= 1) {
+        __syncthreads();   // this tile's rows have landed (vmcnt(0) of every wave), the other buffer is free
+        if (tile + a.G < a.ntiles) issue_tile(tile + a.G, buf ^ 1);
+        const bf16* xs = lds + buf * (DXBUF + NCO * DNPOS * 32);
+        const bf16* ds = xs + DXBUF;
+#pragma unroll
+        for (int ks = 0; ks < DNPOS / 16; ks++) {
+            // positions 16 ks + 8 h ..: output (ks >> 1, ks & 1, 8 h ..): gathered line (2 od, 2 oh), even entries 8 h ..
+            const int rowb = ((2 * (ks >> 1)) * LH + 2 * (ks & 1)) * DLW + 8 * h;
+            bf16x8 bfrag[NCO];
+#pragma unroll
+            for (int o = 0; o < NCO; o++) bfrag[o] = tr_frag(ds + o * (DNPOS * 32) + (ks * 16 + 8 * h) * 32 + lane_off);
+#pragma unroll
+            for (int t = 0; t < 7; t++) {
+                const bf16x8 afrag = tr_frag(xs + rowb * 32 + toff[t] + lane_off);
+#pragma unroll
+                for (int o = 0; o < NCO; o++)
+                    acc[t][o] = RU3D_MFMA_32X32X16(afrag, bfrag[o], acc[t][o], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 7; t++) {
+        const int tap = wave + 4 * t;
+        if (tap < 27) {
+            float* pp = a.part + ((int64_t)blockIdx.x * 27 + tap) * a.Cin * a.Cout;
+#pragma unroll
+            for (int o = 0; o < NCO; o++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int ci = cit * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                    const int co = (cot + o) * 32 + (lane & 31);
+                    pp[(int64_t)ci * a.Cout + co] = acc[t][o][i];
+                }
+        }
+    }
+}
+
+// ---- dispatch.  mode 2 (default): the LDS-DMA kernel (16-wide tiles, two cout tiles per workgroup when Cout % 64 == 0);
+// mode 1: the register-staged kernel; 0: neither (wgrad_staged_mfma_kernel)
+static int s2_mode() {
+    static const int mode = getenv("RU3D_WGRAD_S2") ? atoi(getenv("RU3D_WGRAD_S2")) : 2;
+    return mode;
+}
+static bool s2_dma(const WgradGeom& g) {
+    return s2_mode() >= 2 && (g.Wo % DW) == 0 &&
+           (int64_t)g.Di * g.Hi * g.Wi * g.ldx < (1ll << 30) && (int64_t)g.Do * g.Ho * g.Wo * g.lddy < (1ll << 30);
+}
+static int s2_nco(const WgradGeom& g) { return (s2_dma(g) && (g.Cout % 64) == 0) ? 2 : 1; }
+static int s2_tw(const WgradGeom& g) { return s2_dma(g) ? DW : TWO; }
 
 static int s2_groups(const WgradGeom& g, int64_t ntiles) {
     const int pairs = (g.Cin / 32) * (g.Cout / (32 * s2_nco(g)));
-    int64_t G = 256 / pairs;            // one workgroup per CU (112 KB of LDS each)
+    int64_t G = 256 / pairs;            // one workgroup per CU (112-123 KB of LDS each)
     if (G < 1) G = 1;
     if (G > ntiles) G = ntiles;
     return (int)G;
@@ -181,34 +329,41 @@ static int s2_groups(const WgradGeom& g, int64_t ntiles) {
 }  // namespace
 
 bool wgrad_s2_eligible(const WgradGeom& g) {
-    static const int mode = getenv("RU3D_WGRAD_S2") ? atoi(getenv("RU3D_WGRAD_S2")) : 1;
-    if (!mode || g.k != 3 || g.stride != 2 || g.pad != 1 || (g.Cin % 32) || (g.Cout % 32) || (g.ldx % 8) || (g.lddy % 8))
+    if (!s2_mode() || g.k != 3 || g.stride != 2 || g.pad != 1 || (g.Cin % 32) || (g.Cout % 32) || (g.ldx % 8) || (g.lddy % 8))
         return false;
-    if ((g.Wo % TWO) || (g.Ho % THO) || (g.Do % TDO)) return false;
+    const int tw = s2_tw(g);
+    if ((g.Wo % tw) || (g.Ho % THO) || (g.Do % TDO)) return false;
     const int pairs = (g.Cin / 32) * (g.Cout / (32 * s2_nco(g)));
-    const int64_t ntiles = (int64_t)g.N * (g.Do / TDO) * (g.Ho / THO) * (g.Wo / TWO);
+    const int64_t ntiles = (int64_t)g.N * (g.Do / TDO) * (g.Ho / THO) * (g.Wo / tw);
     return pairs <= 32 && ntiles * pairs >= 192 && ntiles <= 0x7fffffff;
 }
 
 size_t wgrad_s2_ws_bytes(const WgradGeom& g) {
     if (!wgrad_s2_eligible(g)) return 0;
-    const int64_t ntiles = (int64_t)g.N * (g.Do / TDO) * (g.Ho / THO) * (g.Wo / TWO);
+    const int64_t ntiles = (int64_t)g.N * (g.Do / TDO) * (g.Ho / THO) * (g.Wo / s2_tw(g));
     return (size_t)s2_groups(g, ntiles) * 27 * g.Cin * g.Cout * sizeof(float);
 }
 
 int wgrad_s2_launch(const void* x, const void* dy, float* dw, void* ws, const WgradGeom& g, hipStream_t st) {
     if (!wgrad_s2_eligible(g)) return ru3d_fail(-1, "wgrad_s2: shape not supported");
+    const int tw = s2_tw(g), nco = s2_nco(g);
     WS2Args a;
     a.x = (const bf16*)x;
     a.dy = (const bf16*)dy;
     a.part = (float*)ws;
     a.N = g.N; a.Di = g.Di; a.Hi = g.Hi; a.Wi = g.Wi; a.Do = g.Do; a.Ho = g.Ho; a.Wo = g.Wo;
     a.Cin = g.Cin; a.Cout = g.Cout; a.ldx = g.ldx; a.lddy = g.lddy;
-    a.tiles_d = g.Do / TDO; a.tiles_h = g.Ho / THO; a.tiles_w = g.Wo / TWO;
+    a.tiles_d = g.Do / TDO; a.tiles_h = g.Ho / THO; a.tiles_w = g.Wo / tw;
     a.ntiles = g.N * a.tiles_d * a.tiles_h * a.tiles_w;
     a.G = s2_groups(g, a.ntiles);
-    const dim3 grid(a.G, (g.Cin / 32) * (g.Cout / 32));
-    hipLaunchKernelGGL(wgrad3_s2_tile_kernel<1>, grid, dim3(256), 0, st, a);   // NCO = 2 does not fit the register file
+    const dim3 grid(a.G, (g.Cin / 32) * (g.Cout / (32 * nco)));
+    if (s2_dma(g)) {
+        if ((((uintptr_t)x) | ((uintptr_t)dy)) % 16) return ru3d_fail(-1, "wgrad_s2: x / dy must be 16-byte aligned");
+        if (nco == 2) hipLaunchKernelGGL(wgrad3_s2_dma_kernel<2>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(wgrad3_s2_dma_kernel<1>, grid, dim3(256), 0, st, a);
+    } else {
+        hipLaunchKernelGGL(wgrad3_s2_tile_kernel<1>, grid, dim3(256), 0, st, a);
+    }
     int rc = ru3d_check_launch("wgrad3_s2_tile");
     if (rc) return rc;
     return wgrad_reduce_launch((const float*)ws, dw, a.G, 27, g.Cin, g.Cout, g.s_o, g.s_i, st);

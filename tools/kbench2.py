@@ -33,6 +33,8 @@ pw_11a = ops.pack_weight(w_11a, N.ROLE_CONV_FWD, torch.bfloat16, 1)
 pw_11b = ops.pack_weight(w_11b, N.ROLE_CONV_FWD, torch.bfloat16, 1)
 MB = 1e6
 cases = [
+    ("wgrad k3 s2 32->64 (128^3 x, 64^3 dy)", lambda: ops.conv_wgrad(x128_32, x64_64, 3, 2), (268.4 + 67.1)),
+    ("convT wgrad 64->32 (64^3 x, 128^3 dy)", lambda: ops.convt_wgrad(x64_64, x128_32), (268.4 + 67.1)),
     ("conv k3 s2 32->64 fwd   128^3->64^3", lambda: ops.conv_fwd(x128_32, pw_dn, b64, 64, 3, 2), (268.4 + 67.1)),
     ("conv k3 s2 32->64 dgrad 64^3->128^3", lambda: ops.conv_dgrad(x64_64, pw_dn_d, (2, 32, 128, 128, 128), 3, 2), (67.1 + 268.4)),
     ("convT k3 s2 64->32 fwd  64^3->128^3", lambda: ops.convt_fwd(x64_64, pw_up, b32, 32), (67.1 + 268.4)),
