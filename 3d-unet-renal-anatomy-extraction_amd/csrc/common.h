@@ -38,6 +38,31 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define RU3D_WAVE 64
 
+// LDS-DMA: `buffer_load_dwordx4 ... lds` - every lane fetches 16 bytes at its own byte offset inside the buffer (zeros
+// when the offset lies beyond the descriptor's range) and the wave's 64 pieces land in 1 KB of consecutive LDS starting
+// at `lds_dst` (wave-uniform).  Issued as inline asm on purpose: for the builtin form the compiler drains vmcnt in front
+// of the next LDS read it cannot prove disjoint - i.e. right behind the issue, which serialises the fill of the NEXT
+// tile with the reads of the current one.  The caller owns the ordering: `s_waitcnt vmcnt(..)` + barrier before the
+// destination is read (ru3d_dma_landed_barrier).  Counts in vmcnt like any vector-memory load.
+typedef __attribute__((ext_vector_type(4))) int ru3d_i32x4;
+__device__ __forceinline__ ru3d_i32x4 ru3d_buffer_rsrc(const void* base, int num_bytes) {
+    const uint64_t p = (uint64_t)base;
+    ru3d_i32x4 r = {(int)(uint32_t)p, (int)((uint32_t)(p >> 32) & 0xffffu), num_bytes, 0x00020000};
+    return r;
+}
+__device__ __forceinline__ void ru3d_lds_dma16(const ru3d_i32x4& rsrc, const void* lds_dst, int byte_offset) {
+    const uint32_t dst = (uint32_t)(uintptr_t)lds_dst;      // the low 32 bits of a flat LDS address are the LDS offset
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :
+                 : "s"(dst), "v"(byte_offset), "s"(rsrc)
+                 : "memory", "m0");
+}
+// every wave's LDS-DMA fills have landed and every wave has arrived: the filled buffer may be read, the buffer read
+// before this point may be refilled
+__device__ __forceinline__ void ru3d_dma_landed_barrier() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 int ru3d_fail(int code, const char* fmt, ...);   // sets the thread-local error string, returns code
 int ru3d_check_launch(const char* what);         // hipGetLastError -> status
 

@@ -237,8 +237,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s2_dma_kernel(WS2Args a) {
         const int id0 = 2 * od0 - 1, ih0 = 2 * oh0 - 1, iw0 = 2 * ow0 - 1;
         const bool interior = id0 >= 0 && id0 + LD <= a.Di && ih0 >= 0 && ih0 + LH <= a.Hi && iw0 >= 0 && iw0 + DLW <= a.Wi;
         const int org = (((id0 * a.Hi + ih0) * a.Wi + iw0) * a.ldx + cit * 32) * 2;   // may be negative on a border tile
-        __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)n * (xsample_b / 2)), (short)0,
-                                                                      xsample_b, 0x00020000);
+        const ru3d_i32x4 rx = ru3d_buffer_rsrc(a.x + (int64_t)n * (xsample_b / 2), xsample_b);
         bf16* xb = lds + buf * (DXBUF + NCO * DNPOS * 32);
 #pragma unroll
         for (int i = 0; i < DXI; i++) {
@@ -248,27 +247,24 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s2_dma_kernel(WS2Args a) {
                     const int id = id0 + (zz[i] & 255), ih = ih0 + ((zz[i] >> 8) & 255), iw = iw0 + ((zz[i] >> 16) & 255);
                     ok = ok && id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
                 }
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xb + (wave + 4 * i) * 512),
-                                                         16, ok ? org + rel[i] : (int)0x80000000, 0, 0, 0);
+                ru3d_lds_dma16(rx, xb + (wave + 4 * i) * 512, ok ? org + rel[i] : (int)0x80000000);
             }
         }
         // DY rows: instruction j = wave + 4 o of NCO * 4: cout tile o, positions 16 wave + (lane >> 2), piece lane & 3
-        __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (int64_t)n * (dsample_b / 2)), (short)0,
-                                                                      dsample_b, 0x00020000);
+        const ru3d_i32x4 rd = ru3d_buffer_rsrc(a.dy + (int64_t)n * (dsample_b / 2), dsample_b);
         const int pos = 16 * wave + (lane >> 2);
         const int od = od0 + (pos >> 5), oh = oh0 + ((pos >> 4) & 1), ow = ow0 + (pos & 15);
         const int doff = (((od * a.Ho + oh) * a.Wo + ow) * a.lddy + cot * 32 + (lane & 3) * 8) * 2;
         bf16* db = xb + DXBUF;
 #pragma unroll
         for (int o = 0; o < NCO; o++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (__attribute__((address_space(3))) void*)(db + o * (DNPOS * 32) + wave * 512),
-                                                     16, doff + o * 64, 0, 0, 0);
+            ru3d_lds_dma16(rd, db + o * (DNPOS * 32) + wave * 512, doff + o * 64);
     };
 
     if ((int)blockIdx.x < a.ntiles) issue_tile(blockIdx.x, 0);
     int buf = 0;
     for (int tile = blockIdx.x; tile < a.ntiles; tile += a.G, buf ^= 1) {
-        __syncthreads();   // this tile's rows have landed (vmcnt(0) of every wave), the other buffer is free
+        ru3d_dma_landed_barrier();   // this tile's rows have landed, the other buffer is free
         if (tile + a.G < a.ntiles) issue_tile(tile + a.G, buf ^ 1);
         const bf16* xs = lds + buf * (DXBUF + NCO * DNPOS * 32);
         const bf16* ds = xs + DXBUF;

@@ -421,7 +421,9 @@ def test_conv_with_channel_pitch_and_odd_extents(dtype):
                                    (3, 64, 128, 12, 16, 64), (2, 64, 32, 32, 32, 64), (1, 64, 32, 8, 8, 32),
                                    # more columns than workgroups: a workgroup finishes one column's last plane inside the
                                    # next column's first step, across a change of sample
-                                   (6, 32, 32, 16, 64, 128), (5, 32, 64, 8, 64, 128)])
+                                   (6, 32, 32, 16, 64, 128), (5, 32, 64, 8, 64, 128),
+                                   # deep-level shapes: the LDS-DMA weight gradient (two cout tiles per workgroup), ragged too
+                                   (2, 128, 128, 16, 16, 16), (1, 256, 256, 8, 8, 8), (2, 128, 64, 9, 10, 20)])
 def test_mfma_conv_s1_bf16(shape):
     """The bf16 MFMA implicit-GEMM kernel (3x3x3, stride 1) on ragged extents, with bias + residual, as a
     forward conv and as the tap-reversed input gradient, and the wgrad of the same shapes.  Reference:
