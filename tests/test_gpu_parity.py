@@ -467,7 +467,11 @@ def test_mfma_conv_s1_bf16(shape):
                                                     (16, 32, 3, 1, (4, 5, 9)), (48, 96, 3, 2, (6, 6, 6)),
                                                     (32, 64, 3, 2, (31, 32, 66)), (64, 128, 3, 2, (32, 30, 34)),
                                                     (32, 64, 3, 2, (63, 64, 98)), (64, 32, 1, 1, (40, 48, 56)),
-                                                    (32, 64, 3, 2, (32, 32, 128))])
+                                                    (32, 64, 3, 2, (32, 32, 128)),
+                                                    # the LDS-DMA stride-2 weight gradient: 16-wide tiles, one / two cout
+                                                    # tiles per workgroup, every tile touching a border
+                                                    (32, 64, 3, 2, (32, 32, 64)), (64, 128, 3, 2, (16, 32, 64)),
+                                                    (32, 32, 3, 2, (32, 64, 64))])
 def test_mfma_direct_conv_forms_bf16(cin, cout, k, stride, dims):
     """Direct-load MFMA kernel: 1x1x1 (stride 1/2), 3x3x3 stride 2, Cin % 32 != 0; forward (gather form),
     input gradient (transposed form for stride 2) with a fused residual, on ragged extents."""
