@@ -83,6 +83,7 @@ SIGNATURES = {
     "ru3d_ncdhw_to_ndhwc": (_i, [_vp, _P, _i, _vp]),
     "ru3d_ndhwc_to_ncdhw": (_i, [_P, _vp, _i, _vp]),
     "ru3d_loss_state_bytes": (_sz, [_i]),
+    "ru3d_loss_state_bad_labels_offset": (_sz, []),
     "ru3d_loss_workspace_bytes": (_sz, [_i, _i64, _i]),
     "ru3d_loss_fwd": (_i, [_vp, _i64, _i64, _i64, _vp, _i, _i, _i64, _i, _i, _f, _vp, _f, _f, _f, _vp, _vp, _vp,
                            _sz, _vp]),

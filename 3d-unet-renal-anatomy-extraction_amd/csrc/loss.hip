@@ -11,6 +11,7 @@
 //   Hybird  = sum_c w_c (1 - dice_c + focal_c); DiceLoss = sum w (1 - dice); Focal = sum w focal;
 //   Dice    = sum w dice
 #include "common.h"
+#include <stddef.h>
 
 #define RU3D_MAX_CLASSES 8
 
@@ -28,6 +29,8 @@ extern "C" size_t ru3d_loss_state_bytes(int num_classes) {
     (void)num_classes;
     return sizeof(LossState);
 }
+
+extern "C" size_t ru3d_loss_state_bad_labels_offset(void) { return offsetof(LossState, bad_labels); }
 
 static int loss_blocks(int n, int64_t v) {
     int64_t total = (int64_t)n * v;

@@ -14,10 +14,15 @@ logits' device that supports .backward(), .item() and torch.isnan like the refer
 
 Bug-compatible behaviour kept (reference loss.py:68-69, 154-155, 236-237): `weight_c` and the
 class-presence mask are accepted and have no effect; weights are `weight_v / sum|weight_v|`.
-Labels outside [0, C) make the loss NaN (the reference's F.one_hot raises; pass
-`check_labels=True` or set RU3D_CHECK_LABELS=1 to raise here too, at the cost of one sync); with
+Labels outside [0, C) raise `RuntimeError("Class values must be smaller than num_classes.")` like the
+reference's F.one_hot (loss.py:27) - without a host synchronisation of their own: the forward kernel
+counts them into its state block, those 4 bytes ride to pinned host memory behind the kernel, and
+`raise_on_bad_labels()` - called by the next loss call and by `Trainer` right after its own read-back of
+the loss scalars - raises as soon as that copy has landed (the loss value of such a step is NaN).
+`check_labels=True` / RU3D_CHECK_LABELS=1 checks before the launch instead (one sync per call).  With
 C == 1 the reference only works for all-zero targets and so does this.
 """
+import collections
 import os
 
 import torch
@@ -62,6 +67,54 @@ def dice(input, target, alpha=0.5, beta=0.5, smooth=1e-7):
     fn = ((1 - p) * g).sum()
     fp = (p * (1 - g)).sum()
     return (tp + smooth) / (tp + alpha * fn + beta * fp + smooth)
+
+
+# --------------------------------------------------------------------------- deferred label check
+_FLAG_RING = 64
+_flag_host = {}                       # device -> [pinned int32 ring, next slot, events per slot]
+_pending = collections.deque()        # (event, pinned ring, slot) in launch order
+_BAD_LABELS = "Class values must be smaller than num_classes."      # F.one_hot's message (reference loss.py:27)
+
+
+def _note_label_flag(state):
+    """Queue the D2H copy of the forward kernel's out-of-range label count (4 bytes, stream-ordered, no sync)."""
+    dev = state.device
+    if torch.cuda.is_current_stream_capturing():
+        return          # a captured step reports bad labels through its NaN loss only
+    ent = _flag_host.get(dev)
+    if ent is None:
+        ent = _flag_host[dev] = [torch.zeros(_FLAG_RING, dtype=torch.int32).pin_memory(), 0, [None] * _FLAG_RING]
+    ring, slot, events = ent
+    if events[slot] is not None:
+        events[slot].synchronize()      # 64 loss calls behind: long done
+        raise_on_bad_labels()
+    off = _BAD_OFF[0]
+    ring[slot:slot + 1].copy_(state[off:off + 4].view(torch.int32), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    events[slot] = ev
+    _pending.append((ev, ring, slot, events))
+    ent[1] = (slot + 1) % _FLAG_RING
+
+
+def raise_on_bad_labels(wait=False):
+    """Raise F.one_hot's error for every finished loss call that saw a label outside [0, C).  Never blocks unless
+    `wait`: call it right after a read-back of the loss (`.item()`, `.cpu()`) to learn about that very step."""
+    while _pending:
+        ev, ring, slot, events = _pending[0]
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        _pending.popleft()
+        if events[slot] is ev:
+            events[slot] = None
+        if int(ring[slot]) > 0:
+            _pending.clear()
+            raise RuntimeError(_BAD_LABELS)
+
+
+_BAD_OFF = [int(N.lib.ru3d_loss_state_bad_labels_offset())]
 
 
 # --------------------------------------------------------------------------- fused loss
@@ -118,7 +171,8 @@ class _FusedLossFn(torch.autograd.Function):
         if check_labels or c == 1:
             # reference: F.one_hot(target, C) raises for labels >= C (always hit by C == 1 with labels {0,1})
             if lab.numel() and (int(lab.max()) >= c or int(lab.min()) < 0):
-                raise RuntimeError("Class values must be smaller than num_classes.")
+                raise RuntimeError(_BAD_LABELS)
+        raise_on_bad_labels()          # an earlier call's verdict, if it has landed (no wait)
         dev = x.device
         state = torch.empty(N.lib.ru3d_loss_state_bytes(c), dtype=torch.uint8, device=dev)
         out = torch.empty((), dtype=torch.float32, device=dev)
@@ -132,6 +186,8 @@ class _FusedLossFn(torch.autograd.Function):
                                   N.ctypes.cast(wv, N.ctypes.c_void_p) if wv is not None else None, float(alpha),
                                   float(beta), float(smooth), ptr(state), ptr(out), ptr(ws), ws.numel(), stream()),
               "loss_fwd")
+        if not (check_labels or c == 1):
+            _note_label_flag(state)
         ctx.save_for_backward(x, lab, state)
         ctx.meta = (st, lab_code, n, v, c, float(gamma), input.dtype)
         return out

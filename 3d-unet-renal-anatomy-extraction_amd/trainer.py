@@ -37,6 +37,7 @@ except Exception:
     SummaryWriter = None
 
 from loss import dice  # noqa: F401  (re-exported like the reference: trainer.dice)
+import loss as _loss_mod
 from inference import predict_per_patch, predict_case  # noqa: F401  (reference trainer.py:17, 101)
 
 
@@ -156,6 +157,9 @@ class Trainer():
         keys = list(pending[0].keys())
         stacked = torch.stack([torch.stack([p[k].detach().float().reshape(()) for k in keys]) for p in pending])
         values = stacked.cpu().numpy()
+        # the loss kernels' out-of-range label counts travelled in front of these scalars: F.one_hot's error
+        # (reference loss.py:27) instead of a silently skipped NaN step, without a sync of its own
+        _loss_mod.raise_on_bad_labels()
         last = None
         for row in values:
             result = {k: float(v) for k, v in zip(keys, row)}

@@ -172,7 +172,7 @@ def parity_report(args, model, dims, dev, dtype):
            "oracle": "oracle.unet_forward fp32 on the host"}
     was_training = model.training
     model.eval()
-    for name, dt, band in (("bf16" if dtype != torch.float16 else "fp16", dtype, 0.1), ("fp32", torch.float32, 5e-5)):
+    for name, dt, band in (("bf16" if dtype != torch.float16 else "fp16", dtype, 0.05), ("fp32", torch.float32, 5e-5)):
         if dt == torch.float32 and name != "fp32":
             continue
         network.set_compute_dtype(model, dt)

@@ -197,6 +197,9 @@ int ru3d_ndhwc_to_ncdhw(const ru3d_tensor* src, float* dst, int dtype, void* str
  * backward coefficients and the number of out-of-range labels.  loss_out: 1 fp32 on device.
  * C == 1 uses sigmoid with an all-ones one-hot (what F.one_hot(target, 1) yields for valid targets). */
 size_t ru3d_loss_state_bytes(int num_classes);
+/* byte offset, inside the state buffer, of the int32 count of labels outside [0, C) that the forward pass found (the
+ * reference's F.one_hot raises for them, loss.py:27): a host can read these 4 bytes at its next read-back. */
+size_t ru3d_loss_state_bad_labels_offset(void);
 size_t ru3d_loss_workspace_bytes(int n, int64_t v, int num_classes);
 int ru3d_loss_fwd(const float* logits, int64_t stride_n, int64_t stride_c, int64_t stride_v, const void* labels,
                   int label_dtype, int n, int64_t v, int num_classes, int kind, float gamma, const float* weight_v,

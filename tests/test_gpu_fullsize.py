@@ -129,8 +129,9 @@ def test_training_step_is_deterministic_bf16():
 
 def test_config2_forward_fp32_vs_cpu_oracle_full_patch():
     """ResUnet3D(4,32,1,3) on a full 128^3 patch (N = 1 to keep the CPU side ~10 s), fp32 parity mode vs the
-    CPU oracle on identical weights: logits within 2e-3 abs (5 InstanceNorm-separated levels of fp32 noise),
-    argmax may differ only where the oracle's top-2 margin is below 5e-3, per-class Dice of the masks > 0.999."""
+    CPU oracle on identical weights: logits within 5e-5 abs (measured 3e-6 - 7e-6 across boxes), argmax may differ
+    only where the oracle's top-2 margin is below 5e-5 (measured: 0 - 1 flipped voxels of 2,097,152), at most 8 flips,
+    per-class Dice of the masks > 0.9999."""
     model = _config2(torch.float32).eval()
     w = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     x = O.synth_image((1, 1, S, S, S), 4321)
@@ -138,15 +139,16 @@ def test_config2_forward_fp32_vs_cpu_oracle_full_patch():
         got = model(x.to(DEV)).cpu()
         torch.set_num_threads(min(16, torch.get_num_threads()))
         ref = O.unet_forward(x, w, 4)
-    assert (got - ref).abs().max().item() < 2e-3
+    assert (got - ref).abs().max().item() < 5e-5
     top2 = ref.topk(2, dim=1).values
     margin = top2[:, 0] - top2[:, 1]
     flips = got.argmax(1) != ref.argmax(1)
-    assert not (flips & (margin > 5e-3)).any()
+    assert not (flips & (margin > 5e-5)).any()
+    assert int(flips.sum()) <= 8
     for c in range(3):
         a, b = (got.argmax(1) == c).float(), (ref.argmax(1) == c).long()
         if b.sum() > 0:
-            assert O.tversky(a, b).item() > 0.999
+            assert O.tversky(a, b).item() > 0.9999
 
 
 # --------------------------------------------------------------------------- BASELINE config 5 (F = 64, P = 5, 192^3)

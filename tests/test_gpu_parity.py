@@ -4,6 +4,7 @@ the reference and against the CPU oracle.  Needs a real MI355X: run with `-m gpu
 Tolerances (fp32 parity mode): logits/activations 1e-4 abs (values are O(1)), gradients 1e-3 relative
 to the tensor's max magnitude; argmax masks must be bit-identical on the fixtures.  bf16 mode
 tolerances are stated in the bf16 tests."""
+import math
 import os
 
 import numpy as np
@@ -174,10 +175,24 @@ def test_loss_uint8_labels_legacy_names_and_quirks(golden_dir):
     import json
     q = json.load(open(os.path.join(golden_dir, "g4_quirks.json")))
     assert abs(L.HybirdLoss()(x1, torch.zeros_like(y1)).item() - q["c1_all_zero_target_value"]) <= 2e-6
-    # out-of-range label with C > 1: NaN by default, raises when asked to check
+    # out-of-range label with C > 1 raises F.one_hot's error (reference loss.py:27) - by default at the read-back of the
+    # step's loss (no sync of its own), before the launch when asked to check
     xb = O.synth_image((1, 3, 4, 4, 4), 79).to(DEV)
     yb = torch.full((1, 4, 4, 4), 3, dtype=torch.int64, device=DEV)
-    assert torch.isnan(L.HybirdLoss()(xb, yb))
+    L.raise_on_bad_labels(wait=True)                 # nothing pending from the calls above
+    bad = L.HybirdLoss()(xb, yb)
+    assert math.isnan(bad.item())                    # the read-back ...
+    with pytest.raises(RuntimeError, match="Class values must be smaller than num_classes"):
+        L.raise_on_bad_labels()                      # ... has the verdict behind it
+    L.raise_on_bad_labels(wait=True)                 # reported once
+    L.HybirdLoss()(xb, yb)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError):                # the next loss call reports it too
+        L.HybirdLoss()(xb, yb.clamp(max=2))
+    L.raise_on_bad_labels(wait=True)
+    good = L.HybirdLoss()(xb, yb.clamp(max=2))
+    assert math.isfinite(good.item())
+    L.raise_on_bad_labels(wait=True)
     strict = L.HybirdLoss()
     strict.check_labels = True
     with pytest.raises(RuntimeError):
@@ -225,7 +240,7 @@ def test_g1_whole_net_fp32(golden_dir):
     _close(logits, ref, 0, 1e-4, "logits")
     flips = logits.argmax(1).to(torch.uint8).cpu() != torch.from_numpy(z["argmax"])
     margin = (ref[:, 0] - ref[:, 1]).abs()
-    assert int(flips.sum()) <= 16 and not (flips & (margin > 5e-5)).any(), "argmax differs beyond fp32 noise"
+    assert int(flips.sum()) <= 5 and not (flips & (margin > 5e-5)).any(), "argmax differs beyond fp32 noise"
     # Dice between the two masks (the BASELINE 'Dice vs CPU ref' metric) must be 1 to 3 decimals (3 flipped voxels of 32768 here)
     a = logits.argmax(1).cpu()
     b = torch.from_numpy(z["argmax"]).long()
@@ -348,8 +363,8 @@ def test_g1_whole_net_bf16(golden_dir):
     (oracle.set_storage): every inter-kernel tensor and weight rounded to bf16, exact arithmetic inside
     each op.  The HIP path must be no worse than 1.3x that model's distance from the float64 truth (the
     two carry statistically equivalent rounding noise; measured 0.32-0.37 relative L2 on encoder weight
-    gradients for both), logits within 0.1 abs of the fp32 reference, argmax flips only where the
-    reference's top-2 margin is below 0.1, loss within 2e-3."""
+    gradients for both), logits within 0.05 abs of the fp32 reference (measured 0.015), argmax flips only where the
+    reference's top-2 margin is below 0.05, loss within 2e-3."""
     z, model = _g1_model(golden_dir)
     network.set_compute_dtype(model, torch.bfloat16)
     model.eval()
@@ -359,10 +374,10 @@ def test_g1_whole_net_bf16(golden_dir):
     assert logits.dtype == torch.float32
     ref = torch.from_numpy(z["logits"])
     got = logits.detach().cpu()
-    assert (got - ref).abs().max().item() <= 0.1
+    assert (got - ref).abs().max().item() <= 0.05
     margin = (ref[:, 0] - ref[:, 1]).abs()
     flips = got.argmax(1) != ref.argmax(1)
-    assert not (flips & (margin > 0.1)).any()
+    assert not (flips & (margin > 0.05)).any()
     assert flips.float().mean().item() < 0.02
     l = L.HybirdLoss()(logits, y)
     assert abs(l.item() - float(z["loss/hybird"])) <= 2e-3

@@ -170,3 +170,19 @@ def test_checkpoint_resume_identical_next_step(tmp_path):
     assert r1["loss"] == r2["loss"]
     for (k, a), (_, b) in zip(model.state_dict().items(), model2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_fit_raises_on_out_of_range_labels():
+    """A label >= num_classes does not vanish into a skipped NaN step: Trainer raises F.one_hot's error (reference
+    loss.py:27 through trainer.py:486) at its read-back of that step's scalars."""
+    model = _model()
+    data = Cases(2)
+    data.items[1]["label"] = data.items[1]["label"].clone()
+    data.items[1]["label"][0, 0, 0] = 2          # the model has two classes
+    L.raise_on_bad_labels(wait=True)
+    tr = T.Trainer(model=model, optimizer=torch.optim.Adam(model.parameters(), lr=1e-4), loss=L.HybirdLoss(),
+                   dataset=data, batch_size=1, valid_split=0.0, dataloader_kwargs={"num_workers": 0}, sync_every=1,
+                   progress=False)
+    with pytest.raises(RuntimeError, match="Class values must be smaller than num_classes"):
+        tr.fit(num_epochs=1)
+    L.raise_on_bad_labels(wait=True)
