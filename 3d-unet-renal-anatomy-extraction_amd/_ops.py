@@ -292,6 +292,39 @@ def convt_fwd(x, pw, bias, cout):
     return y
 
 
+def convt_fwd_in(x, pw, bias, cout):
+    """ConvTranspose3d + far pad and the InstanceNorm statistics of its output in one entry point (fused in the
+    transposed conv's epilogue where the stride-2 tile kernel takes the shape)."""
+    n, _, d, h, w = x.shape
+    y = N.new_act(n, cout, 2 * d, 2 * h, 2 * w, x.dtype, x.device)
+    mean = torch.empty(n * cout, dtype=torch.float32, device=x.device)
+    scale = torch.empty(n * cout, dtype=torch.float32, device=x.device)
+    b = _bias(bias)
+    dx, dyy = desc(x), desc(y)
+    code = N.dtype_code(x.dtype)
+    ws = N.workspace(N.lib.ru3d_convtranspose3d_k3s2p1_fwd_in_workspace_bytes(ref(dx), ref(dyy), code), x.device)
+    check(N.lib.ru3d_convtranspose3d_k3s2p1_fwd_in(ref(dx), ptr(pw), ptr(b), ref(dyy), ptr(mean), ptr(scale), ptr(ws),
+                                                   ws.numel(), IN_EPS, code, stream()), "convtranspose3d_fwd_in")
+    return y, mean, scale
+
+
+def conv_s2_dgrad_pair(dy, pw3, dy2, pw1, in_shape, res=None):
+    """Input gradient of a pooling ResBlock's conv1 (k3 s2) and skip_conv (k1 s2) plus `res` in one launch; None when
+    the shapes have no fused kernel (the caller then chains two conv_dgrad calls)."""
+    n, cin, d, h, w = in_shape
+    code = N.dtype_code(dy.dtype)
+    if code == N.F32:
+        return None
+    dx = N.new_act(n, cin, d, h, w, dy.dtype, dy.device)
+    ddy, ddy2, ddx = desc(dy), desc(dy2), desc(dx)
+    dr = desc(res) if res is not None else None
+    if not N.lib.ru3d_conv3d_s2_dgrad_pair_supported(ref(ddy), ref(ddy2), ref(dr), ref(ddx), code):
+        return None
+    check(N.lib.ru3d_conv3d_s2_dgrad_pair(ref(ddy), ptr(pw3), ref(ddy2), ptr(pw1), ref(dr), ref(ddx), code, stream()),
+          "conv3d_s2_dgrad_pair")
+    return dx
+
+
 def convt_dgrad(dy, pw, in_shape):
     n, cin, d, h, w = in_shape
     dx = N.new_act(n, cin, d, h, w, dy.dtype, dy.device)
@@ -724,8 +757,11 @@ class ResBlockFn(torch.autograd.Function):
                 parked = None
                 if ctx.in_link is not None:
                     parked, ctx.in_link.grad = ctx.in_link.grad, None
-                gx0 = conv_dgrad(gpre, pwsd, tuple(x.shape), 1, stride, res=parked)
-                gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gx0)
+                if stride == 2:     # both stride-2 input gradients (+ the parked concat share) in one launch
+                    gx = conv_s2_dgrad_pair(dy1, pw1d, gpre, pwsd, tuple(x.shape), res=parked)
+                if gx is None:
+                    gx0 = conv_dgrad(gpre, pwsd, tuple(x.shape), 1, stride, res=parked)
+                    gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gx0)
         elif need_gx:
             gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gpre)
         _join(dev, gw1, gw2, gws, gbs)
@@ -758,8 +794,7 @@ class UpFn(torch.autograd.Function):
             specs.append((bt, N.ROLE_BIAS, 1, cout_seg, 0))
         packs = pack_weights(specs, sd)
         btp = _f32_view(packs[-1], cout_p) if (cout_seg and bt is not None) else bt
-        y = convt_fwd(x, packs[0], btp, cout_p)
-        mean, scale = in_stats(y)
+        y, mean, scale = convt_fwd_in(x, packs[0], btp, cout_p)
         n, _, d, h, w = y.shape
         if skip is not None:
             skip = as_grad(skip, sd)

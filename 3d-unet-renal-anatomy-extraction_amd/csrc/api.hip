@@ -328,6 +328,44 @@ extern "C" int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, co
     return run_conv(dy, w_packed, nullptr, res, dx, k, stride, 1, 0, 0, dtype, dtype, as_stream(stream));
 }
 
+// ---- the two stride-2 convs of a pooling ResBlock: their input gradients in one launch (conv_s2.hip, T form)
+static ConvGeom s2_dgrad_geom(const ru3d_tensor* dy, const ru3d_tensor* res, const ru3d_tensor* dx) {
+    ConvGeom g;
+    g.N = dy->n;
+    g.Di = dy->d; g.Hi = dy->h; g.Wi = dy->w; g.Cin = dy->c; g.ldx = dy->ld;
+    g.Do = dx->d; g.Ho = dx->h; g.Wo = dx->w; g.Cout = dx->c; g.ldy = dx->ld;
+    g.CoutPad = generic_cout_pad(dx->c);
+    g.ldr = res ? res->ld : 0;
+    g.k = 3; g.stride = 2; g.pad = 1;
+    g.transposed = 1; g.zero_far = 0; g.flip = 0;
+    return g;
+}
+
+extern "C" int ru3d_conv3d_s2_dgrad_pair_supported(const ru3d_tensor* dy, const ru3d_tensor* dy2, const ru3d_tensor* res,
+                                                   const ru3d_tensor* dx, int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_s2_dgrad_pair_supported_f16(dy, dy2, res, dx, dtype));
+    if (dtype != RU3D_BF16 || !tensor_ok(dy) || !tensor_ok(dy2) || !tensor_ok(dx) || !res_ok(res, dx)) return 0;
+    if (dy2->n != dy->n || dy2->d != dy->d || dy2->h != dy->h || dy2->w != dy->w || dy2->c != dy->c) return 0;
+    if (dx->n != dy->n || dy->d != conv_out(dx->d, 3, 2) || dy->h != conv_out(dx->h, 3, 2) || dy->w != conv_out(dx->w, 3, 2))
+        return 0;
+    if ((dy2->ld % 8) || (int64_t)dy2->d * dy2->h * dy2->w * dy2->ld >= (1ll << 30)) return 0;
+    if ((((uintptr_t)dy->ptr) | ((uintptr_t)dy2->ptr) | ((uintptr_t)dx->ptr) | (res ? (uintptr_t)res->ptr : 0)) % 16) return 0;
+    return convt_s2_tile_eligible(s2_dgrad_geom(dy, res, dx)) ? 1 : 0;
+}
+
+extern "C" int ru3d_conv3d_s2_dgrad_pair(const ru3d_tensor* dy, const void* w3_packed, const ru3d_tensor* dy2,
+                                         const void* w1_packed, const ru3d_tensor* res, const ru3d_tensor* dx, int dtype,
+                                         void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_s2_dgrad_pair_f16(dy, w3_packed, dy2, w1_packed, res, dx, dtype, stream));
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(w3_packed && w1_packed, "conv3d_s2_dgrad_pair: null weight");
+    RU3D_REQUIRE(ru3d_conv3d_s2_dgrad_pair_supported(dy, dy2, res, dx, dtype),
+                 "conv3d_s2_dgrad_pair: shapes have no fused kernel (ask ru3d_conv3d_s2_dgrad_pair_supported first)");
+    const ConvGeom g = s2_dgrad_geom(dy, res, dx);
+    return convt_s2_tile_launch(dy->ptr, w3_packed, nullptr, res ? res->ptr : nullptr, dx->ptr, g, nullptr, dy2->ptr,
+                                dy2->ld, w1_packed, as_stream(stream));
+}
+
 // ---- conv input gradient followed by the InstanceNorm + LeakyReLU backward of the tensor it differentiates
 static ConvGeom dgrad_s1_geom(const ru3d_tensor* dy, const ru3d_tensor* da, int k) {
     ConvGeom g = fwd_geom(dy, da, k, 1);
@@ -448,6 +486,59 @@ extern "C" int ru3d_convtranspose3d_k3s2p1_fwd(const ru3d_tensor* x, const void*
     RU3D_REQUIRE(convt_shapes_ok(x, y) && w_packed, "convtranspose3d_fwd: y must have extents 2*x");
     RU3D_REQUIRE(dtype_ok(dtype), "convtranspose3d_fwd: bad dtype");
     return run_conv(x, w_packed, bias, nullptr, y, 3, 2, 1, 0, 1, dtype, dtype, as_stream(stream));
+}
+
+static ConvGeom convt_fwd_geom(const ru3d_tensor* x, const ru3d_tensor* y) {
+    ConvGeom g;
+    g.N = x->n;
+    g.Di = x->d; g.Hi = x->h; g.Wi = x->w; g.Cin = x->c; g.ldx = x->ld;
+    g.Do = y->d; g.Ho = y->h; g.Wo = y->w; g.Cout = y->c; g.ldy = y->ld;
+    g.CoutPad = generic_cout_pad(y->c);
+    g.ldr = 0;
+    g.k = 3; g.stride = 2; g.pad = 1;
+    g.transposed = 1; g.zero_far = 1; g.flip = 0;
+    return g;
+}
+
+static bool convt_fwd_in_fused(const ru3d_tensor* x, const ru3d_tensor* y, int dtype) {
+    return dtype == RU3D_BF16 && convt_shapes_ok(x, y) && mfma_conv_eligible(x->c, y->c, 3, dtype, dtype) &&
+           ((((uintptr_t)x->ptr) | ((uintptr_t)y->ptr)) % 16) == 0 && convt_s2_tile_eligible(convt_fwd_geom(x, y));
+}
+
+extern "C" size_t ru3d_convtranspose3d_k3s2p1_fwd_in_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* y, int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_convtranspose3d_k3s2p1_fwd_in_workspace_bytes_f16(x, y, dtype));
+    if (!tensor_ok(x) || !tensor_ok(y)) return 0;
+    size_t need = ru3d_reduce_workspace_bytes(y);
+    if (convt_fwd_in_fused(x, y, dtype)) {
+        const size_t slab = convt_s2_tile_slab_bytes(convt_fwd_geom(x, y));
+        if (slab > need) need = slab;
+    }
+    return need;
+}
+
+extern "C" int ru3d_convtranspose3d_k3s2p1_fwd_in(const ru3d_tensor* x, const void* w_packed, const float* bias,
+                                                  const ru3d_tensor* y, float* mean, float* scale, void* ws,
+                                                  size_t ws_bytes, float eps, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_convtranspose3d_k3s2p1_fwd_in_f16(x, w_packed, bias, y, mean, scale, ws, ws_bytes, eps, dtype, stream));
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(convt_shapes_ok(x, y) && w_packed && mean && scale && ws, "convtranspose3d_fwd_in: bad argument");
+    RU3D_REQUIRE(ws_bytes >= ru3d_convtranspose3d_k3s2p1_fwd_in_workspace_bytes(x, y, dtype),
+                 "convtranspose3d_fwd_in: workspace too small");
+    if (convt_fwd_in_fused(x, y, dtype)) {
+        const ConvGeom g = convt_fwd_geom(x, y);
+        const size_t slab = convt_s2_tile_slab_bytes(g);
+        hipError_t e = hipMemsetAsync(ws, 0, slab, as_stream(stream));   // (workgroup, wave, sample) triples that never meet add 0
+        if (e != hipSuccess) return ru3d_fail((int)e, "convtranspose3d_fwd_in: memset failed: %s", hipGetErrorString(e));
+        int rc = convt_s2_tile_launch(x->ptr, w_packed, bias, nullptr, y->ptr, g, (float*)ws, nullptr, 0, nullptr, as_stream(stream));
+        if (rc) return rc;
+        int gx, cb;
+        if (convt_s2_tile_slab_geom(g, &gx, &cb)) return ru3d_fail(-1, "convtranspose3d_fwd_in: no slab geometry");
+        return stats_slab_finalize_launch((const float*)ws, gx, cb, g.N, g.Cout, 1.0 / ((double)g.Do * g.Ho * g.Wo), nullptr, eps,
+                                          mean, scale, as_stream(stream));
+    }
+    int rc = ru3d_convtranspose3d_k3s2p1_fwd(x, w_packed, bias, y, dtype, stream);
+    if (rc) return rc;
+    return ru3d_instnorm_stats(y, nullptr, mean, scale, ws, ws_bytes, eps, dtype, stream);
 }
 
 extern "C" int ru3d_convtranspose3d_k3s2p1_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* dx,

@@ -86,6 +86,10 @@ bool mfma_conv_can_fuse_stats(const ConvGeom& g);
 size_t mfma_conv_stats_slab_bytes(const ConvGeom& g);
 int mfma_conv_stats_finalize(const ConvGeom& g, const float* slab, const float* drop, float eps, float* mean,
                              float* scale, hipStream_t st);
+// slab[(y * gx + workgroup) * 4 + wave][n][cb][2] of per-wave (sum, sum of squares) -> mean / scale (or, scale == NULL,
+// the two means)
+int stats_slab_finalize_launch(const float* slab, int gx, int cb, int N, int C, double invV, const float* drop, float eps,
+                               float* mean, float* scale, hipStream_t st);
 // the sliding 32-channel kernel can take the InstanceNorm + LeakyReLU backward sums of its output (input-gradient role)
 bool mfma_conv_can_fuse_bwd_sums(const ConvGeom& g);
 // slab of backward sums -> m12[n][c] = (mean g', mean g' xhat)
@@ -110,6 +114,13 @@ int conv_slide_launch(const void* x, const void* w, const float* bias, const voi
 bool slide64_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* out);
 int conv_slide64_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
                         float* stat_slab, hipStream_t st);
+
+// conv_s2.hip (the stride-2 forms of the large levels: LDS-DMA plane ring, producer wave, weights in registers)
+bool convt_s2_tile_eligible(const ConvGeom& g);
+size_t convt_s2_tile_slab_bytes(const ConvGeom& g);
+int convt_s2_tile_slab_geom(const ConvGeom& g, int* gx, int* cb);
+int convt_s2_tile_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
+                         float* stat_slab, const void* x2, int ldx2, const void* w2, hipStream_t st);
 
 // wgrad_slide.hip (3x3x3 stride-1 weight gradient on the large levels: D-sliding plane ring)
 struct WgradSlidePlan {

@@ -762,6 +762,13 @@ __global__ __launch_bounds__(256) void stats_slab_finalize_kernel(const float* _
     }
 }
 
+int stats_slab_finalize_launch(const float* slab, int gx, int cb, int N, int C, double invV, const float* drop, float eps,
+                               float* mean, float* scale, hipStream_t st) {
+    dim3 grid((C + 3) / 4, N);
+    hipLaunchKernelGGL(stats_slab_finalize_kernel, grid, dim3(256), 0, st, slab, gx, cb, N, C, invV, drop, eps, mean, scale);
+    return ru3d_check_launch("stats_slab_finalize");
+}
+
 bool mfma_conv_can_fuse_bwd_sums(const ConvGeom& g) {
     if (!(g.k == 3 && g.stride == 1 && !g.transposed && g.Cin == 32)) return false;
     SlidePlan sp;
@@ -1516,6 +1523,10 @@ static int launch_direct(const void* x, const void* w, const float* bias, const 
         }
         return ru3d_check_launch("conv_direct_ksplit");
     }
+    // the large levels' stride-2 forms: LDS-DMA plane ring + producer wave + weights in registers (conv_s2.hip)
+    if (g.transposed && convt_s2_tile_eligible(g) &&
+        ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res)) % 16) == 0)
+        return convt_s2_tile_launch(x, w, bias, res, y, g, nullptr, nullptr, 0, nullptr, st);
     static const int tile_mode = getenv("RU3D_CONVT_TILE") ? atoi(getenv("RU3D_CONVT_TILE")) : 1;
     if (tile_mode && g.transposed && g.k == 3 && g.pad == 1) {
         // (TD+1)(TH+1)(TW+1) rows of Cin*2+16 bytes must fit in LDS: Cin <= 256 with the 16-wide tile, 128 with the 32-wide

@@ -121,6 +121,16 @@ int ru3d_conv3d_fwd_in(const ru3d_tensor* x, const void* w_packed, const float* 
 int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* res,
                       const ru3d_tensor* dx, int k, int stride, int dtype, void* ws, size_t ws_bytes,
                       void* stream);
+/* The input gradient of a pooling ResBlock's two stride-2 convs in ONE launch (reference network.py:394 conv1 k3 s2 p1
+ * and :403 skip_conv k1 s2, both applied to the block's input, :406-411):
+ *     dx = conv3_dgrad(dy; w3_packed) + conv1_dgrad(dy2; w1_packed) (+ res)
+ * dy and dy2 live on the same (pooled) grid with the same channel count.  `_supported` says whether a fused kernel
+ * exists for the shapes (the caller otherwise chains two ru3d_conv3d_dgrad calls through `res`). */
+int ru3d_conv3d_s2_dgrad_pair_supported(const ru3d_tensor* dy, const ru3d_tensor* dy2, const ru3d_tensor* res,
+                                        const ru3d_tensor* dx, int dtype);
+int ru3d_conv3d_s2_dgrad_pair(const ru3d_tensor* dy, const void* w3_packed, const ru3d_tensor* dy2,
+                              const void* w1_packed, const ru3d_tensor* res, const ru3d_tensor* dx, int dtype,
+                              void* stream);
 /* weight gradient, written as fp32 in the reference layout [Cout][Cin][k^3] (param.grad). */
 size_t ru3d_conv3d_wgrad_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* dy, int k, int stride, int dtype);
 int ru3d_conv3d_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, float* dw, void* ws, size_t ws_bytes,
@@ -130,6 +140,12 @@ int ru3d_conv3d_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, float* dw, vo
  * y has extents 2*x.{d,h,w}; its far planes are written as exact zeros (no bias there). */
 int ru3d_convtranspose3d_k3s2p1_fwd(const ru3d_tensor* x, const void* w_packed, const float* bias,
                                     const ru3d_tensor* y, int dtype, void* stream);
+/* The same followed by the InstanceNorm statistics of y (network.py:315; the zero far planes count): mean / scale as
+ * ru3d_instnorm_stats writes them; fused into the transposed conv's epilogue where a kernel for the shape exists. */
+size_t ru3d_convtranspose3d_k3s2p1_fwd_in_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* y, int dtype);
+int ru3d_convtranspose3d_k3s2p1_fwd_in(const ru3d_tensor* x, const void* w_packed, const float* bias,
+                                       const ru3d_tensor* y, float* mean, float* scale, void* ws, size_t ws_bytes,
+                                       float eps, int dtype, void* stream);
 /* dy must have zero far planes (ru3d_in_lrelu_bwd(zero_far=1) guarantees it). */
 int ru3d_convtranspose3d_k3s2p1_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* dx,
                                       int dtype, void* stream);
