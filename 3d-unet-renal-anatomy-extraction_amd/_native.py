@@ -60,6 +60,9 @@ SIGNATURES = {
     "ru3d_conv3d_fwd_in_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),
     "ru3d_conv3d_fwd_in": (_i, [_P, _vp, _vp, _P, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _f, _vp]),
     "ru3d_conv3d_dgrad": (_i, [_P, _vp, _P, _P, _i, _i, _i, _vp, _sz, _vp]),
+    "ru3d_conv3d_s2_pair_fwd_in_supported": (_i, [_P, _P, _P, _i]),
+    "ru3d_conv3d_s2_pair_fwd_in_workspace_bytes": (_sz, [_P, _P, _i]),
+    "ru3d_conv3d_s2_pair_fwd_in": (_i, [_P, _vp, _vp, _P, _vp, _vp, _P, _vp, _vp, _vp, _vp, _sz, _f, _i, _vp]),
     "ru3d_conv3d_s2_dgrad_pair_supported": (_i, [_P, _P, _P, _P, _i]),
     "ru3d_conv3d_s2_dgrad_pair": (_i, [_P, _vp, _P, _vp, _P, _P, _i, _vp]),
     "ru3d_conv3d_wgrad_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),

@@ -308,6 +308,28 @@ def convt_fwd_in(x, pw, bias, cout):
     return y, mean, scale
 
 
+def conv_s2_pair_fwd_in(x, pw3, b3, pw1, b1, cout, drop_scale=None):
+    """conv1 (k3 s2) with its InstanceNorm statistics and skip_conv (k1 s2) of the same input in one launch:
+    (y3, mean, scale, y1), or None when the shapes have no fused kernel."""
+    code = N.dtype_code(x.dtype)
+    if code == N.F32:
+        return None
+    n, _, d, h, w = x.shape
+    od, oh, ow = _conv_out(d, 3, 2), _conv_out(h, 3, 2), _conv_out(w, 3, 2)
+    y3 = N.new_act(n, cout, od, oh, ow, x.dtype, x.device)
+    y1 = N.new_act(n, cout, od, oh, ow, x.dtype, x.device)
+    dx, d3, d1 = desc(x), desc(y3), desc(y1)
+    if not N.lib.ru3d_conv3d_s2_pair_fwd_in_supported(ref(dx), ref(d3), ref(d1), code):
+        return None
+    mean = torch.empty(n * cout, dtype=torch.float32, device=x.device)
+    scale = torch.empty(n * cout, dtype=torch.float32, device=x.device)
+    ws = N.workspace(N.lib.ru3d_conv3d_s2_pair_fwd_in_workspace_bytes(ref(dx), ref(d3), code), x.device)
+    check(N.lib.ru3d_conv3d_s2_pair_fwd_in(ref(dx), ptr(pw3), ptr(_bias(b3)), ref(d3), ptr(pw1), ptr(_bias(b1)), ref(d1),
+                                           ptr(drop_scale), ptr(mean), ptr(scale), ptr(ws), ws.numel(), IN_EPS, code,
+                                           stream()), "conv3d_s2_pair_fwd_in")
+    return y3, mean, scale, y1
+
+
 def conv_s2_dgrad_pair(dy, pw3, dy2, pw1, in_shape, res=None):
     """Input gradient of a pooling ResBlock's conv1 (k3 s2) and skip_conv (k1 s2) plus `res` in one launch; None when
     the shapes have no fused kernel (the caller then chains two conv_dgrad calls)."""
@@ -689,10 +711,16 @@ class ResBlockFn(torch.autograd.Function):
             it = iter(packs[nw:])
             b1, b2, bs = [(_f32_view(next(it), cout_p) if b is not None else None) for b in (b1, b2, bs)]
         pw1, pw2 = packs[0], packs[1]
-        y1, mean1, scale1 = conv_fwd_in(x, pw1, b1, cout_p, 3, stride, drop_scale)
+        fused = conv_s2_pair_fwd_in(x, pw1, b1, packs[2], bs, cout_p, drop_scale) if (ws is not None and stride == 2) else None
+        if fused is not None:       # pooling block: conv1 + its statistics and the skip conv from one read of x
+            y1, mean1, scale1, skip = fused
+        else:
+            y1, mean1, scale1 = conv_fwd_in(x, pw1, b1, cout_p, 3, stride, drop_scale)
         a1 = in_lrelu_fwd(y1, mean1, scale1)
         y2, mean2, scale2 = conv_fwd_in(a1, pw2, b2, cout_p, 3, 1)
-        if ws is not None:
+        if fused is not None:
+            pass
+        elif ws is not None:
             skip = conv_fwd(x, packs[2], bs, cout_p, 1, stride)
         else:
             skip = x

@@ -35,6 +35,7 @@ extern "C" const char* ru3d_last_error(void) { return g_last_error.c_str(); }
 
 namespace RU3D_NS {
 
+static ConvGeom fwd_geom(const ru3d_tensor* x, const ru3d_tensor* y, int k, int stride);
 static bool dtype_ok(int d) { return d == RU3D_F32 || d == RU3D_BF16; }   // fp32 or this build's 16-bit type
 static int conv_out(int in, int k, int s) { return (in + 2 * (k / 2) - k) / s + 1; }
 
@@ -326,6 +327,45 @@ extern "C" int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, co
     if (stride == 1)
         return run_conv(dy, w_packed, nullptr, res, dx, k, 1, 0, 1, 0, dtype, dtype, as_stream(stream), ws, ws_bytes);
     return run_conv(dy, w_packed, nullptr, res, dx, k, stride, 1, 0, 0, dtype, dtype, as_stream(stream));
+}
+
+// ---- the two stride-2 convs of a pooling ResBlock: forward of both + InstanceNorm sums in one launch (conv_s2.hip, G form)
+extern "C" int ru3d_conv3d_s2_pair_fwd_in_supported(const ru3d_tensor* x, const ru3d_tensor* y3, const ru3d_tensor* y1, int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_s2_pair_fwd_in_supported_f16(x, y3, y1, dtype));
+    if (dtype != RU3D_BF16 || !tensor_ok(x) || !tensor_ok(y3) || !tensor_ok(y1)) return 0;
+    if (y3->n != x->n || y3->d != conv_out(x->d, 3, 2) || y3->h != conv_out(x->h, 3, 2) || y3->w != conv_out(x->w, 3, 2)) return 0;
+    if (y1->n != y3->n || y1->d != y3->d || y1->h != y3->h || y1->w != y3->w || y1->c != y3->c) return 0;
+    if ((y1->ld % 4) || (int64_t)y1->d * y1->h * y1->w * y1->ld >= (1ll << 30)) return 0;
+    if ((((uintptr_t)x->ptr) % 16) || ((((uintptr_t)y3->ptr) | ((uintptr_t)y1->ptr)) % 8)) return 0;
+    return conv_s2_tile_eligible(fwd_geom(x, y3, 3, 2)) ? 1 : 0;
+}
+
+extern "C" size_t ru3d_conv3d_s2_pair_fwd_in_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* y3, int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_s2_pair_fwd_in_workspace_bytes_f16(x, y3, dtype));
+    if (!tensor_ok(x) || !tensor_ok(y3)) return 0;
+    return conv_s2_tile_slab_bytes(fwd_geom(x, y3, 3, 2));
+}
+
+extern "C" int ru3d_conv3d_s2_pair_fwd_in(const ru3d_tensor* x, const void* w3_packed, const float* b3, const ru3d_tensor* y3,
+                                          const void* w1_packed, const float* b1, const ru3d_tensor* y1,
+                                          const float* drop_scale, float* mean, float* scale, void* ws, size_t ws_bytes,
+                                          float eps, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_s2_pair_fwd_in_f16(x, w3_packed, b3, y3, w1_packed, b1, y1, drop_scale, mean, scale, ws, ws_bytes, eps, dtype, stream));
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(w3_packed && w1_packed && mean && scale && ws, "conv3d_s2_pair_fwd_in: null argument");
+    RU3D_REQUIRE(ru3d_conv3d_s2_pair_fwd_in_supported(x, y3, y1, dtype),
+                 "conv3d_s2_pair_fwd_in: shapes have no fused kernel (ask ru3d_conv3d_s2_pair_fwd_in_supported first)");
+    const ConvGeom g = fwd_geom(x, y3, 3, 2);
+    const size_t slab = conv_s2_tile_slab_bytes(g);
+    RU3D_REQUIRE(ws_bytes >= slab, "conv3d_s2_pair_fwd_in: workspace too small");
+    hipError_t e = hipMemsetAsync(ws, 0, slab, as_stream(stream));
+    if (e != hipSuccess) return ru3d_fail((int)e, "conv3d_s2_pair_fwd_in: memset failed: %s", hipGetErrorString(e));
+    int rc = conv_s2_tile_launch(x->ptr, w3_packed, b3, y3->ptr, g, (float*)ws, w1_packed, b1, y1->ptr, y1->ld, as_stream(stream));
+    if (rc) return rc;
+    int gx, cb;
+    if (conv_s2_tile_slab_geom(g, &gx, &cb)) return ru3d_fail(-1, "conv3d_s2_pair_fwd_in: no slab geometry");
+    return stats_slab_finalize_launch((const float*)ws, gx, cb, g.N, g.Cout, 1.0 / ((double)g.Do * g.Ho * g.Wo), drop_scale, eps,
+                                      mean, scale, as_stream(stream));
 }
 
 // ---- the two stride-2 convs of a pooling ResBlock: their input gradients in one launch (conv_s2.hip, T form)

@@ -122,6 +122,12 @@ int convt_s2_tile_slab_geom(const ConvGeom& g, int* gx, int* cb);
 int convt_s2_tile_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
                          float* stat_slab, const void* x2, int ldx2, const void* w2, hipStream_t st);
 
+bool conv_s2_tile_eligible(const ConvGeom& g);
+size_t conv_s2_tile_slab_bytes(const ConvGeom& g);
+int conv_s2_tile_slab_geom(const ConvGeom& g, int* gx, int* cb);
+int conv_s2_tile_launch(const void* x, const void* w, const float* bias, void* y, const ConvGeom& g, float* stat_slab,
+                        const void* w2, const float* bias2, void* y2, int ldy2, hipStream_t st);
+
 // wgrad_slide.hip (3x3x3 stride-1 weight gradient on the large levels: D-sliding plane ring)
 struct WgradSlidePlan {
     int dsplit, DL, tiles_h, tiles_w, units, G, pairs;

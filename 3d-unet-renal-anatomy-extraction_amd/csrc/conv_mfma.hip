@@ -1527,6 +1527,8 @@ static int launch_direct(const void* x, const void* w, const float* bias, const 
     if (g.transposed && convt_s2_tile_eligible(g) &&
         ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res)) % 16) == 0)
         return convt_s2_tile_launch(x, w, bias, res, y, g, nullptr, nullptr, 0, nullptr, st);
+    if (!g.transposed && !res && conv_s2_tile_eligible(g) && (((uintptr_t)x) % 16) == 0 && (((uintptr_t)y) % 8) == 0)
+        return conv_s2_tile_launch(x, w, bias, y, g, nullptr, nullptr, nullptr, nullptr, 0, st);
     static const int tile_mode = getenv("RU3D_CONVT_TILE") ? atoi(getenv("RU3D_CONVT_TILE")) : 1;
     if (tile_mode && g.transposed && g.k == 3 && g.pad == 1) {
         // (TD+1)(TH+1)(TW+1) rows of Cin*2+16 bytes must fit in LDS: Cin <= 256 with the 16-wide tile, 128 with the 32-wide

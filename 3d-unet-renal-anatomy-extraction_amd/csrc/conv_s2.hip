@@ -506,6 +506,228 @@ constexpr size_t t_lds_bytes(bool x2) {
     return (size_t)TGeom<CIN, TW>::RING * TGeom<CIN, TW>::PLANE_B + (x2 ? 2 * TGeom<CIN, TW>::X2_B : 0);
 }
 
+
+// --------------------------------------------------------------------------------------------------- G form
+// out[od, oh, ow] = sum_k in[2 od - 1 + kd, 2 oh - 1 + kh, 2 ow - 1 + kw] . W[k]: a workgroup owns TH x GW output positions
+// and slides along the output's D; step od needs the input planes 2 od - 1 .. 2 od + 1 (two new ones per step, ring of
+// five).  A staged plane is 2 TH + 1 lines of 2 GW + 1 rows, every line de-interleaved by the parity of w: GW + 1 odd rows
+// (w = 2 (c0 + e) - 1) followed by GW even ones (w = 2 (c0 + e)) - the 16 positions of a tap's fragment are then 16
+// consecutive rows: kw = 0 -> odd rows e = p, kw = 1 -> even rows e = p, kw = 2 -> odd rows e = p + 1.
+constexpr int GW = 16;
+template <int CIN>
+struct GGeom {
+    static constexpr int KS = CIN / 32;
+    static constexpr int PITCH_B = CIN * 2 + 32;
+    static constexpr int LINE = 2 * GW + 1, NODD = GW + 1, LINES = 2 * TH + 1, ROWS = LINES * LINE;
+    static constexpr int ND = (ROWS * PITCH_B + 1023) / 1024;
+    static constexpr int PLANE_B = ND * 1024;
+    static constexpr int RING = 5;
+};
+
+template <int CIN, bool HAS_STATS, bool HAS_Y2>
+__device__ __forceinline__ void g_consumer(const S2Args& a, const char* lds, int wave) {
+    using GM = GGeom<CIN>;
+    constexpr int KS = GM::KS;
+    const int lane = threadIdx.x & 63;
+    const int p = lane & 15, g4 = lane >> 4;
+    const int cb = blockIdx.y * 64 + 16 * wave;        // the wave's 16 output channels
+    const int NTT = a.cout_total / 32;
+
+    // ---- weights: [tap][k-step], A fragment lane -> output channel cb + (lane & 15), k-block lane >> 4
+    bf16x8 wreg[27 * KS];
+    static_for<0, 27>([&](auto tc) {
+        constexpr int tap = decltype(tc)::value;
+        const int wtap = a.flip ? 26 - tap : tap;
+        static_for<0, KS>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value;
+            wreg[tap * KS + ks] = a.w[packed_unit(wtap, CIN / 16, NTT, cb + p, ks * 4 + g4)];
+        });
+    });
+    bf16x8 w2reg[HAS_Y2 ? KS : 1];
+    if constexpr (HAS_Y2) {
+        static_for<0, KS>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value;
+            w2reg[ks] = a.w2[packed_unit(0, CIN / 16, NTT, cb + p, ks * 4 + g4)];
+        });
+    }
+    float bias4[4], bias24[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        bias4[i] = a.bias ? a.bias[cb + 4 * g4 + i] : 0.f;
+        bias24[i] = (HAS_Y2 && a.bias2) ? a.bias2[cb + 4 * g4 + i] : 0.f;
+    }
+
+    float st1[4], st2[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) st1[i] = st2[i] = 0.f;
+    int cur_n = -1;
+    auto stat_flush = [&]() {
+        if (!HAS_STATS || cur_n < 0) return;
+        float* dst = a.stat_slab + ((((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * a.N + cur_n) * 64) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float s1 = st1[i], s2 = st2[i];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {       // lanes with equal g4 hold the same 4 channels
+                s1 += __shfl_xor(s1, o, 64);
+                s2 += __shfl_xor(s2, o, 64);
+            }
+            if (p == 0) {
+                dst[(16 * wave + 4 * g4 + i) * 2] = s1;
+                dst[(16 * wave + 4 * g4 + i) * 2 + 1] = s2;
+            }
+            st1[i] = st2[i] = 0.f;
+        }
+    };
+
+    const char* const lane_lds = lds + p * GM::PITCH_B + g4 * 16;
+    const int y_lane = (p * a.ldy + cb + 4 * g4) * 2, y2_lane = (p * a.ldy2 + cb + 4 * g4) * 2;
+    const int ysample_b = a.Do * a.Ho * a.Wo * a.ldy * 2, y2sample_b = a.Do * a.Ho * a.Wo * a.ldy2 * 2;
+
+    const int Gx = gridDim.x;
+    const bool remap = (a.units % 8) == 0 && (Gx % 8) == 0;
+    for (int ui = blockIdx.x; ui < a.units; ui += Gx) {
+        int u = remap ? (ui % 8) * (a.units / 8) + ui / 8 : ui;
+        const int tw_i = u % a.tiles_w;
+        u /= a.tiles_w;
+        const int th_i = u % a.tiles_h;
+        u /= a.tiles_h;
+        const int dc = u % a.dsplit;
+        const int n = u / a.dsplit;
+        const int d0 = dc * a.DL, b0 = th_i * TH, c0 = tw_i * GW;
+        int dl = a.Do - d0;
+        if (dl > a.DL) dl = a.DL;
+        if (HAS_STATS && n != cur_n) {
+            stat_flush();
+            cur_n = n;
+        }
+        const rsrc_t ry = make_rsrc(a.y + (int64_t)n * (ysample_b / 2), ysample_b);
+        rsrc_t ry2 = ry;
+        if constexpr (HAS_Y2) ry2 = make_rsrc(a.y2 + (int64_t)n * (y2sample_b / 2), y2sample_b);
+        const bool lane_in = c0 + p < a.Wo && !(a.dbg & 1);
+
+        consumer_barrier();      // prologue planes have landed
+        for (int s = 0; s < dl; s++) {
+            const int od = d0 + s;
+            int slot[3];
+#pragma unroll
+            for (int kd = 0; kd < 3; kd++) slot[kd] = ((2 * s + kd) % GM::RING) * GM::PLANE_B;
+            static_for<0, TH>([&](auto hc) {
+                constexpr int hb = decltype(hc)::value;
+                f32x4 acc = {bias4[0], bias4[1], bias4[2], bias4[3]};
+                f32x4 acc2 = {bias24[0], bias24[1], bias24[2], bias24[3]};
+                static_for<0, 27>([&](auto tc) {
+                    constexpr int tap = decltype(tc)::value;
+                    constexpr int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                    constexpr int row = (2 * hb + kh) * GM::LINE + (kw == 1 ? GM::NODD : (kw >> 1));
+                    static_for<0, KS>([&](auto kc) {
+                        constexpr int ks = decltype(kc)::value;
+                        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(lane_lds + slot[kd] + row * GM::PITCH_B + ks * 64);
+                        acc = RU3D_MFMA_16X16X32(wreg[tap * KS + ks], xb, acc, 0, 0, 0);
+                        if constexpr (HAS_Y2 && tap == 13) acc2 = RU3D_MFMA_16X16X32(w2reg[ks], xb, acc2, 0, 0, 0);
+                    });
+                });
+                // (wait states between the last MFMA and the VALU read of its result: see the T form)
+                asm("s_nop 7\n\ts_nop 4" : "+v"(acc), "+v"(acc2));
+                const bool ok = lane_in && b0 + hb < a.Ho;
+                const int uni = (od * a.Ho + b0 + hb) * a.Wo + c0;
+                const bf16x4 o = __builtin_convertvector(acc, bf16x4);
+                if constexpr (HAS_STATS) {
+                    if (ok) {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            const float f = (float)o[i];
+                            st1[i] += f;
+                            st2[i] = fmaf(f, f, st2[i]);
+                        }
+                    }
+                }
+                {
+                    typedef int i32x2v __attribute__((ext_vector_type(2)));
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2v, o), ry, ok ? y_lane : OOB, uni * a.ldy * 2, 0);
+                    if constexpr (HAS_Y2) {
+                        const bf16x4 o2 = __builtin_convertvector(acc2, bf16x4);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2v, o2), ry2, ok ? y2_lane : OOB,
+                                                              uni * a.ldy2 * 2, 0);
+                    }
+                }
+            });
+            consumer_barrier();      // done with planes 2 s, 2 s + 1; the next two have landed
+        }
+    }
+    stat_flush();
+}
+
+template <int CIN>
+__device__ __forceinline__ void g_producer(const S2Args& a, char* lds) {
+    using GM = GGeom<CIN>;
+    const int lane = threadIdx.x & 63;
+    // tile-invariant part of every DMA slot: (line zh, w relative to 2 c0 as dw + 1 in 0..2 GW, byte column) or -1
+    int slot_id[GM::ND];
+#pragma unroll
+    for (int i = 0; i < GM::ND; i++) {
+        const int byte = i * 1024 + lane * 16;
+        const int row = byte / GM::PITCH_B, col = byte - row * GM::PITCH_B;
+        const bool ok = row < GM::ROWS && col < CIN * 2;
+        const int zh = row / GM::LINE, r = row - zh * GM::LINE;
+        const int dw1 = r < GM::NODD ? 2 * r : 2 * (r - GM::NODD) + 1;      // (w - (2 c0 - 1)): odd rows 0, 2, .., even rows 1, 3, ..
+        slot_id[i] = ok ? (zh | (dw1 << 8) | (col << 16)) : -1;
+    }
+    const int plane_b = a.Hi * a.Wi * a.ldx * 2, sample_b = a.Di * plane_b;
+
+    const int Gx = gridDim.x;
+    const bool remap = (a.units % 8) == 0 && (Gx % 8) == 0;
+    for (int ui = blockIdx.x; ui < a.units; ui += Gx) {
+        int u = remap ? (ui % 8) * (a.units / 8) + ui / 8 : ui;
+        const int tw_i = u % a.tiles_w;
+        u /= a.tiles_w;
+        const int th_i = u % a.tiles_h;
+        u /= a.tiles_h;
+        const int dc = u % a.dsplit;
+        const int n = u / a.dsplit;
+        const int d0 = dc * a.DL, b0 = th_i * TH, c0 = tw_i * GW;
+        int dl = a.Do - d0;
+        if (dl > a.DL) dl = a.DL;
+
+        int voff[GM::ND];
+#pragma unroll
+        for (int i = 0; i < GM::ND; i++) {
+            const int id = slot_id[i];
+            const int ih = 2 * b0 - 1 + (id & 255), iw = 2 * c0 - 1 + ((id >> 8) & 255);
+            voff[i] = (id >= 0 && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi && !(a.dbg & 2)) ? (ih * a.Wi + iw) * a.ldx * 2 + (id >> 16) : OOB;
+        }
+        const bf16* xs = a.x + (int64_t)n * (sample_b / 2);
+        auto issue_plane = [&](int j) {          // relative plane j: input plane 2 d0 - 1 + j -> ring slot j % RING
+            const int pl = 2 * d0 - 1 + j;
+            const bool inside = pl >= 0 && pl < a.Di;
+            const ru3d_i32x4 rs = ru3d_buffer_rsrc(xs, inside ? sample_b : 0);
+            const int base = inside ? pl * plane_b : 0;
+            char* dst = lds + (j % GM::RING) * GM::PLANE_B;
+#pragma unroll
+            for (int i = 0; i < GM::ND; i++) ru3d_lds_dma16(rs, dst + i * 1024, voff[i] + base);
+        };
+        issue_plane(0);
+        issue_plane(1);
+        issue_plane(2);
+        producer_barrier();
+        for (int s = 0; s < dl; s++) {
+            if (s + 1 < dl) {
+                issue_plane(2 * s + 3);
+                issue_plane(2 * s + 4);
+            }
+            producer_barrier();
+        }
+    }
+}
+
+template <int CIN, bool HAS_STATS, bool HAS_Y2>
+__global__ __launch_bounds__(320) void conv3_s2_tile_kernel(S2Args a) {
+    extern __shared__ __attribute__((aligned(1024))) char lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave == NCONS) g_producer<CIN>(a, lds_raw);
+    else g_consumer<CIN, HAS_STATS, HAS_Y2>(a, lds_raw, wave);
+}
+
 }  // namespace
 
 // --------------------------------------------------------------------------------------------------- host: T form
@@ -636,6 +858,106 @@ int convt_s2_tile_launch(const void* x, const void* w, const float* bias, const 
     a.dbg = dbg;
     if (tw == 32) return t_launch<64, 32>(a, p, res != nullptr, stat_slab != nullptr, x2 != nullptr, st);
     return t_launch<64, 16>(a, p, res != nullptr, stat_slab != nullptr, x2 != nullptr, st);
+}
+
+// --------------------------------------------------------------------------------------------------- host: G form
+static bool g_plan(int N, int Do, int Ho, int Wo, int Cin, int Cout, SlidePlan* out) {
+    static const int mode = getenv("RU3D_CONV_S2") ? atoi(getenv("RU3D_CONV_S2")) : 1;
+    if (!mode || Cin != 32 || (Cout % 64) || Cout > 128 || Do < 2) return false;
+    const int ny = Cout / 64;
+    const int64_t cols = (int64_t)N * ((Ho + TH - 1) / TH) * ((Wo + GW - 1) / GW);
+    int64_t best_cost = -1;
+    int best_ds = 0;
+    for (int ds = 1; ds <= Do; ds++) {
+        const int dl = (Do + ds - 1) / ds;
+        if ((int64_t)dl * (ds - 1) >= Do) continue;
+        const int64_t units = cols * ds;
+        int64_t gx = 256 / ny;
+        if (gx > units) gx = units;
+        const int64_t cost = ((units + gx - 1) / gx) * (int64_t)(2 * dl + 3);      // planes through a workgroup
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best_ds = ds;
+        }
+    }
+    if (!best_ds) return false;
+    const int64_t units = cols * best_ds;
+    if (units * ny < 128 || units > 0x7fffffff) return false;
+    out->dsplit = best_ds;
+    out->DL = (Do + best_ds - 1) / best_ds;
+    out->tiles_h = (Ho + TH - 1) / TH;
+    out->tiles_w = (Wo + GW - 1) / GW;
+    out->units = (int)units;
+    int g = units < 256 / ny ? (int)units : 256 / ny;
+    if ((units % 8) == 0 && g >= 8) g = (g / 8) * 8;
+    out->grid = g;
+    out->ny = ny;
+    return true;
+}
+
+bool conv_s2_tile_eligible(const ConvGeom& g) {
+    SlidePlan sp;
+    if (g.transposed || g.k != 3 || g.stride != 2 || g.pad != 1) return false;
+    if ((g.ldx % 8) || (g.ldy % 4)) return false;
+    if ((int64_t)g.Di * g.Hi * g.Wi * g.ldx >= (1ll << 30) || (int64_t)g.Do * g.Ho * g.Wo * g.ldy >= (1ll << 30)) return false;
+    if (g.Do != (g.Di - 1) / 2 + 1 || g.Ho != (g.Hi - 1) / 2 + 1 || g.Wo != (g.Wi - 1) / 2 + 1) return false;
+    return g_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp);
+}
+
+size_t conv_s2_tile_slab_bytes(const ConvGeom& g) {
+    SlidePlan sp;
+    if (!g_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) return 0;
+    return (size_t)sp.grid * sp.ny * 4 * g.N * 64 * 2 * sizeof(float);
+}
+
+int conv_s2_tile_slab_geom(const ConvGeom& g, int* gx, int* cb) {
+    SlidePlan sp;
+    if (!g_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) return -1;
+    *gx = sp.grid;
+    *cb = 64;
+    return 0;
+}
+
+// w2 / bias2 / y2 (pitch ldy2): the 1x1x1 stride-2 conv of the same input as a second output; stat_slab: sums of y
+int conv_s2_tile_launch(const void* x, const void* w, const float* bias, void* y, const ConvGeom& g, float* stat_slab,
+                        const void* w2, const float* bias2, void* y2, int ldy2, hipStream_t st) {
+    SlidePlan p;
+    if (!conv_s2_tile_eligible(g) || !g_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &p))
+        return ru3d_fail(-1, "conv_s2_tile: shape not supported");
+    if ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)w2)) % 16 || (((uintptr_t)y) | ((uintptr_t)y2)) % 8)
+        return ru3d_fail(-1, "conv_s2_tile: operands must be 16-byte (x, w) / 8-byte (y) aligned");
+    if (y2 && (!w2 || (ldy2 % 4) || (int64_t)g.Do * g.Ho * g.Wo * ldy2 >= (1ll << 30)))
+        return ru3d_fail(-1, "conv_s2_tile: bad second output");
+    S2Args a;
+    a.x = (const bf16*)x; a.w = (const bf16x8*)w; a.bias = bias; a.res = nullptr; a.y = (bf16*)y;
+    a.stat_slab = stat_slab;
+    a.x2 = nullptr; a.w2 = (const bf16x8*)w2; a.bias2 = bias2; a.y2 = (bf16*)y2;
+    a.N = g.N; a.Di = g.Di; a.Hi = g.Hi; a.Wi = g.Wi; a.Do = g.Do; a.Ho = g.Ho; a.Wo = g.Wo;
+    a.ldx = g.ldx; a.ldy = g.ldy; a.ldr = g.ldy; a.ldx2 = g.ldx; a.ldy2 = y2 ? ldy2 : g.ldy;
+    a.flip = g.flip; a.zero_far = 0; a.cout_total = g.Cout;
+    a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w; a.dsplit = p.dsplit; a.DL = p.DL; a.units = p.units;
+    static const int dbg = getenv("RU3D_S2_DBG") ? atoi(getenv("RU3D_S2_DBG")) : 0;
+    a.dbg = dbg;
+    const dim3 grid(p.grid, p.ny), block(320);
+    const size_t lds = (size_t)GGeom<32>::RING * GGeom<32>::PLANE_B;
+#define RU3D_G_LAUNCH(S, Y2)                                                                                      \
+    do {                                                                                                          \
+        auto kern = conv3_s2_tile_kernel<32, S, Y2>;                                                              \
+        static bool attr = false;                                                                                 \
+        if (!attr) {                                                                                              \
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != \
+                hipSuccess)                                                                                       \
+                return ru3d_fail(-1, "conv_s2_tile: cannot raise the dynamic LDS limit");                         \
+            attr = true;                                                                                          \
+        }                                                                                                         \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                        \
+    } while (0)
+    if (stat_slab && y2) RU3D_G_LAUNCH(true, true);
+    else if (stat_slab) RU3D_G_LAUNCH(true, false);
+    else if (y2) RU3D_G_LAUNCH(false, true);
+    else RU3D_G_LAUNCH(false, false);
+#undef RU3D_G_LAUNCH
+    return ru3d_check_launch("conv3_s2_tile");
 }
 
 }  // namespace RU3D_NS

@@ -11,6 +11,9 @@
     X(ru3d_conv3d_fwd_in_workspace_bytes) \
     X(ru3d_conv3d_fwd_in) \
     X(ru3d_conv3d_dgrad) \
+    X(ru3d_conv3d_s2_pair_fwd_in_supported) \
+    X(ru3d_conv3d_s2_pair_fwd_in_workspace_bytes) \
+    X(ru3d_conv3d_s2_pair_fwd_in) \
     X(ru3d_conv3d_s2_dgrad_pair_supported) \
     X(ru3d_conv3d_s2_dgrad_pair) \
     X(ru3d_convtranspose3d_k3s2p1_fwd_in_workspace_bytes) \
@@ -44,6 +47,9 @@
 #define ru3d_conv3d_fwd_in_workspace_bytes ru3d_conv3d_fwd_in_workspace_bytes_f16
 #define ru3d_conv3d_fwd_in ru3d_conv3d_fwd_in_f16
 #define ru3d_conv3d_dgrad ru3d_conv3d_dgrad_f16
+#define ru3d_conv3d_s2_pair_fwd_in_supported ru3d_conv3d_s2_pair_fwd_in_supported_f16
+#define ru3d_conv3d_s2_pair_fwd_in_workspace_bytes ru3d_conv3d_s2_pair_fwd_in_workspace_bytes_f16
+#define ru3d_conv3d_s2_pair_fwd_in ru3d_conv3d_s2_pair_fwd_in_f16
 #define ru3d_conv3d_s2_dgrad_pair_supported ru3d_conv3d_s2_dgrad_pair_supported_f16
 #define ru3d_conv3d_s2_dgrad_pair ru3d_conv3d_s2_dgrad_pair_f16
 #define ru3d_convtranspose3d_k3s2p1_fwd_in_workspace_bytes ru3d_convtranspose3d_k3s2p1_fwd_in_workspace_bytes_f16

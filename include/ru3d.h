@@ -121,6 +121,15 @@ int ru3d_conv3d_fwd_in(const ru3d_tensor* x, const void* w_packed, const float* 
 int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* res,
                       const ru3d_tensor* dx, int k, int stride, int dtype, void* ws, size_t ws_bytes,
                       void* stream);
+/* The forward of a pooling ResBlock's two stride-2 convs of the same input in ONE launch (network.py:394 conv1 k3 s2 p1,
+ * :403 skip_conv k1 s2; :406-411), plus the InstanceNorm statistics of conv1's output as ru3d_conv3d_fwd_in takes them:
+ *     y3 = conv3(x; w3, b3), (mean, scale) = IN statistics of Dropout3d(y3), y1 = conv1(x; w1, b1)
+ * `_supported`: a fused kernel exists for the shapes; workspace: ru3d_conv3d_s2_pair_fwd_in_workspace_bytes. */
+int ru3d_conv3d_s2_pair_fwd_in_supported(const ru3d_tensor* x, const ru3d_tensor* y3, const ru3d_tensor* y1, int dtype);
+size_t ru3d_conv3d_s2_pair_fwd_in_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* y3, int dtype);
+int ru3d_conv3d_s2_pair_fwd_in(const ru3d_tensor* x, const void* w3_packed, const float* b3, const ru3d_tensor* y3,
+                               const void* w1_packed, const float* b1, const ru3d_tensor* y1, const float* drop_scale,
+                               float* mean, float* scale, void* ws, size_t ws_bytes, float eps, int dtype, void* stream);
 /* The input gradient of a pooling ResBlock's two stride-2 convs in ONE launch (reference network.py:394 conv1 k3 s2 p1
  * and :403 skip_conv k1 s2, both applied to the block's input, :406-411):
  *     dx = conv3_dgrad(dy; w3_packed) + conv1_dgrad(dy2; w1_packed) (+ res)

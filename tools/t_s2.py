@@ -87,5 +87,55 @@ if which in ("all", "p"):
         e1 = (mean.cpu().double() - m).abs().max().item(); e2 = (scale.cpu().double() - 1.0 / (v + 1e-5).sqrt()).abs().max().item()
         good = e1 < 1e-5 and e2 < 1e-4
         print("convT fwd_in stats %s: mean err %.3g scale err %.3g %s" % (dims, e1, e2, "ok" if good else "FAIL")); ok &= good
+if which in ("all", "g"):
+    # stride-2 conv forward (bias), odd extents and ragged tiles; ConvTranspose input gradient (the same form over dy)
+    for cin, cout, dims in [(32, 64, (32, 32, 64)), (32, 64, (31, 30, 66)), (32, 64, (63, 64, 98)), (32, 128, (16, 24, 40)),
+                            (32, 64, (64, 64, 64))]:
+        g = torch.Generator().manual_seed(cin + cout + sum(dims))
+        d, h, w = dims
+        xv = torch.randn(2, cin, d, h, w, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, 3, generator=g) * (1.0 / (27 * cin) ** 0.5)
+        b = torch.randn(cout, generator=g)
+        y = ops.conv_fwd(ops.as_input(xv.to(DEV), BF), ops.pack_weight(wt.to(DEV), N.ROLE_CONV_FWD, BF, 2), b.to(DEV), cout, 3, 2)
+        ref = F.conv3d(xv.bfloat16().float(), wt.bfloat16().float(), b, stride=2, padding=1)
+        ok &= close(y, ref, 2 ** -8, "s2 fwd %s %s" % ((cin, cout), dims))
+    for cin, cout, dims in [(64, 32, (16, 16, 32)), (64, 32, (16, 15, 33)), (64, 32, (32, 32, 32))]:
+        g = torch.Generator().manual_seed(cin + cout + sum(dims))
+        d, h, w = dims
+        xv = torch.randn(2, cin, d, h, w, generator=g)
+        wt = torch.randn(cin, cout, 3, 3, 3, generator=g) * (1.0 / (27 * cin / 8) ** 0.5)
+        xr = xv.bfloat16().float().requires_grad_(True)
+        ref = F.pad(F.conv_transpose3d(xr, wt.bfloat16().float(), None, stride=2, padding=1), (0, 1, 0, 1, 0, 1))
+        gy = torch.randn(ref.shape, generator=g)
+        gy[:, :, -1] = 0; gy[:, :, :, -1] = 0; gy[..., -1] = 0
+        gx = ops.convt_dgrad(ops.as_input(gy.to(DEV), BF), ops.pack_weight(wt.to(DEV), N.ROLE_CONVT_DGRAD, BF), tuple(xv.shape))
+        ref.backward(gy.bfloat16().float())
+        ok &= close(gx, xr.grad, 2 ** -8, "convT dgrad %s %s" % ((cin, cout), dims))
+if which in ("all", "f"):
+    # pooling block forward: conv1 + statistics (with a Dropout3d factor) + skip conv in one launch
+    for cin, cout, dims in [(32, 64, (32, 32, 64)), (32, 64, (31, 30, 66)), (32, 64, (64, 64, 64))]:
+        g = torch.Generator().manual_seed(cin + cout + sum(dims))
+        d, h, w = dims
+        xv = torch.randn(3, cin, d, h, w, generator=g)
+        w3 = torch.randn(cout, cin, 3, 3, 3, generator=g) * (1.0 / (27 * cin) ** 0.5)
+        w1 = torch.randn(cout, cin, 1, 1, 1, generator=g) * (1.0 / cin ** 0.5)
+        b3 = torch.randn(cout, generator=g); b1 = torch.randn(cout, generator=g)
+        drop = (torch.rand(3 * cout, generator=g) > 0.5).float() * 2.0
+        x = ops.as_input(xv.to(DEV), BF)
+        out = ops.conv_s2_pair_fwd_in(x, ops.pack_weight(w3.to(DEV), N.ROLE_CONV_FWD, BF, 2), b3.to(DEV),
+                                      ops.pack_weight(w1.to(DEV), N.ROLE_CONV_FWD, BF, 2), b1.to(DEV), cout, drop.to(DEV))
+        if out is None:
+            print("pair fwd %s: no fused kernel" % (dims,)); ok = False; continue
+        y3, mean, scale, y1 = out
+        r3 = F.conv3d(xv.bfloat16().float(), w3.bfloat16().float(), b3, stride=2, padding=1)
+        r1 = F.conv3d(xv.bfloat16().float(), w1.bfloat16().float(), b1, stride=2)
+        ok &= close(y3, r3, 2 ** -8, "pair fwd conv3 %s" % (dims,))
+        ok &= close(y1, r1, 2 ** -8, "pair fwd conv1 %s" % (dims,))
+        yf = y3.float().cpu().double()
+        m = yf.mean(dim=(2, 3, 4)).reshape(-1); v = yf.var(dim=(2, 3, 4), unbiased=False).reshape(-1)
+        sd = drop.double()
+        e1 = (mean.cpu().double() - m).abs().max().item(); e2 = (scale.cpu().double() - sd / (sd * sd * v + 1e-5).sqrt()).abs().max().item()
+        good = e1 < 1e-5 and e2 < 1e-4
+        print("pair fwd stats %s: mean err %.3g scale err %.3g %s" % (dims, e1, e2, "ok" if good else "FAIL")); ok &= good
 print("ALL OK" if ok else "FAILED")
 sys.exit(0 if ok else 1)
