@@ -330,6 +330,22 @@ def conv_s2_pair_fwd_in(x, pw3, b3, pw1, b1, cout, drop_scale=None):
     return y3, mean, scale, y1
 
 
+def conv_s1_dgrad_pair(dy, pw3, dy2, pw1, in_shape):
+    """Input gradient of a decoder ResBlock's conv1 (k3 s1) and skip_conv (k1 s1) in one launch; None when the shapes
+    have no fused kernel."""
+    n, cin, d, h, w = in_shape
+    code = N.dtype_code(dy.dtype)
+    if code == N.F32:
+        return None
+    dx = N.new_act(n, cin, d, h, w, dy.dtype, dy.device)
+    ddy, ddy2, ddx = desc(dy), desc(dy2), desc(dx)
+    if not N.lib.ru3d_conv3d_s1_dgrad_pair_supported(ref(ddy), ref(ddy2), ref(ddx), code):
+        return None
+    check(N.lib.ru3d_conv3d_s1_dgrad_pair(ref(ddy), ptr(pw3), ref(ddy2), ptr(pw1), ref(ddx), code, stream()),
+          "conv3d_s1_dgrad_pair")
+    return dx
+
+
 def conv_s2_dgrad_pair(dy, pw3, dy2, pw1, in_shape, res=None):
     """Input gradient of a pooling ResBlock's conv1 (k3 s2) and skip_conv (k1 s2) plus `res` in one launch; None when
     the shapes have no fused kernel (the caller then chains two conv_dgrad calls)."""
@@ -387,6 +403,22 @@ def in_lrelu_fwd(y, mean, scale, res=None, out=None):
     dr = desc(res) if res is not None else None
     check(N.lib.ru3d_in_lrelu_fwd(ref(dy), ptr(mean), ptr(scale), ref(dr), ref(do), LRELU_SLOPE,
                                   N.dtype_code(y.dtype), stream()), "in_lrelu_fwd")
+    return out
+
+
+def skip1x1_in_lrelu_fwd(x, pw, bias, y, mean, scale, out=None):
+    """lrelu(IN(y) + conv1x1(x)) without storing the skip conv's output; None when the shapes have no fused kernel."""
+    code = N.dtype_code(y.dtype)
+    if code == N.F32:
+        return None
+    if out is None:
+        n, c, d, h, w = y.shape
+        out = N.new_act(n, c, d, h, w, y.dtype, y.device)
+    dx, dy, do = desc(x), desc(y), desc(out)
+    if not N.lib.ru3d_skip1x1_in_lrelu_fwd_supported(ref(dx), ref(dy), ref(do), code):
+        return None
+    check(N.lib.ru3d_skip1x1_in_lrelu_fwd(ref(dx), ptr(pw), ptr(_bias(bias)), ref(dy), ptr(mean), ptr(scale), ref(do),
+                                          LRELU_SLOPE, code, stream()), "skip1x1_in_lrelu_fwd")
     return out
 
 
@@ -718,10 +750,16 @@ class ResBlockFn(torch.autograd.Function):
             y1, mean1, scale1 = conv_fwd_in(x, pw1, b1, cout_p, 3, stride, drop_scale)
         a1 = in_lrelu_fwd(y1, mean1, scale1)
         y2, mean2, scale2 = conv_fwd_in(a1, pw2, b2, cout_p, 3, 1)
+        z = None
         if fused is not None:
             pass
         elif ws is not None:
-            skip = conv_fwd(x, packs[2], bs, cout_p, 1, stride)
+            # decoder block: skip conv + IN apply + sum + LeakyReLU in one pass where a kernel exists (no link buffer then:
+            # decoder outputs are not skips)
+            if stride == 1 and out_link is None:
+                z = skip1x1_in_lrelu_fwd(x, packs[2], bs, y2, mean2, scale2)
+            if z is None:
+                skip = conv_fwd(x, packs[2], bs, cout_p, 1, stride)
         else:
             skip = x
         n_, _, d_, h_, w_ = y2.shape
@@ -731,7 +769,8 @@ class ResBlockFn(torch.autograd.Function):
         zout = None
         if out_link is not None and cout_p * y2.element_size() >= 128:
             zout = out_link.skip_view(n_, cout_p, d_, h_, w_, sd, x.device)
-        z = in_lrelu_fwd(y2, mean2, scale2, res=skip, out=zout)
+        if z is None:
+            z = in_lrelu_fwd(y2, mean2, scale2, res=skip, out=zout)
         bwd = packs[nfwd:nw] + [None] * 3
         if checkpoint and train:
             ctx.save_for_backward(x, None, None, None, z, mean1, scale1, mean2, scale2, bwd[0], bwd[1], bwd[2],
@@ -787,6 +826,8 @@ class ResBlockFn(torch.autograd.Function):
                     parked, ctx.in_link.grad = ctx.in_link.grad, None
                 if stride == 2:     # both stride-2 input gradients (+ the parked concat share) in one launch
                     gx = conv_s2_dgrad_pair(dy1, pw1d, gpre, pwsd, tuple(x.shape), res=parked)
+                elif parked is None:
+                    gx = conv_s1_dgrad_pair(dy1, pw1d, gpre, pwsd, tuple(x.shape))
                 if gx is None:
                     gx0 = conv_dgrad(gpre, pwsd, tuple(x.shape), 1, stride, res=parked)
                     gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gx0)

@@ -329,6 +329,50 @@ extern "C" int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, co
     return run_conv(dy, w_packed, nullptr, res, dx, k, stride, 1, 0, 0, dtype, dtype, as_stream(stream));
 }
 
+// ---- decoder ResBlock: input gradient of conv1 (k3 s1) and skip_conv (k1 s1) in one launch (conv_slide32.hip, 28th tap)
+static ConvGeom dgrad_s1_geom(const ru3d_tensor* dy, const ru3d_tensor* da, int k);
+extern "C" int ru3d_conv3d_s1_dgrad_pair_supported(const ru3d_tensor* dy, const ru3d_tensor* dy2, const ru3d_tensor* dx, int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_s1_dgrad_pair_supported_f16(dy, dy2, dx, dtype));
+    static const int mode = getenv("RU3D_DGRAD_PAIR") ? atoi(getenv("RU3D_DGRAD_PAIR")) : 1;
+    if (!mode || dtype != RU3D_BF16 || !tensor_ok(dy) || !tensor_ok(dy2) || !tensor_ok(dx)) return 0;
+    if (dy2->n != dy->n || dy2->d != dy->d || dy2->h != dy->h || dy2->w != dy->w || dy2->c != dy->c) return 0;
+    if (dx->n != dy->n || dx->d != dy->d || dx->h != dy->h || dx->w != dy->w) return 0;
+    if ((dy->ld % 8) || (dy2->ld % 8) || (dx->ld % 8)) return 0;
+    if ((((uintptr_t)dy->ptr) | ((uintptr_t)dy2->ptr) | ((uintptr_t)dx->ptr)) % 16) return 0;
+    if ((int64_t)dy->d * dy->h * dy->w * dy->ld >= (1ll << 30)) return 0;
+    const ConvGeom g = dgrad_s1_geom(dy, dx, 3);
+    return (mfma_conv_eligible(g.Cin, g.Cout, 3, dtype, dtype) && mfma_conv_can_fuse_partner(g)) ? 1 : 0;
+}
+
+extern "C" int ru3d_conv3d_s1_dgrad_pair(const ru3d_tensor* dy, const void* w3_packed, const ru3d_tensor* dy2,
+                                         const void* w1_packed, const ru3d_tensor* dx, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_s1_dgrad_pair_f16(dy, w3_packed, dy2, w1_packed, dx, dtype, stream));
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(w3_packed && w1_packed, "conv3d_s1_dgrad_pair: null weight");
+    RU3D_REQUIRE(ru3d_conv3d_s1_dgrad_pair_supported(dy, dy2, dx, dtype),
+                 "conv3d_s1_dgrad_pair: shapes have no fused kernel (ask ru3d_conv3d_s1_dgrad_pair_supported first)");
+    const ConvGeom g = dgrad_s1_geom(dy, dx, 3);
+    return conv_mfma_launch(dy->ptr, w3_packed, nullptr, nullptr, dx->ptr, g, as_stream(stream), nullptr, nullptr, 0, nullptr, 0,
+                            0.f, dy2->ptr, dy2->ld, w1_packed);
+}
+
+// ---- decoder ResBlock tail: skip conv + InstanceNorm apply + sum + LeakyReLU (fused_skip.hip)
+extern "C" int ru3d_skip1x1_in_lrelu_fwd_supported(const ru3d_tensor* x, const ru3d_tensor* y, const ru3d_tensor* out, int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_skip1x1_in_lrelu_fwd_supported_f16(x, y, out, dtype));
+    return skip1x1_fused_eligible(x, y, out, dtype) ? 1 : 0;
+}
+
+extern "C" int ru3d_skip1x1_in_lrelu_fwd(const ru3d_tensor* x, const void* w_packed, const float* bias, const ru3d_tensor* y,
+                                         const float* mean, const float* scale, const ru3d_tensor* out, float slope, int dtype,
+                                         void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_skip1x1_in_lrelu_fwd_f16(x, w_packed, bias, y, mean, scale, out, slope, dtype, stream));
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(w_packed && mean && scale, "skip1x1_in_lrelu_fwd: null argument");
+    RU3D_REQUIRE(skip1x1_fused_eligible(x, y, out, dtype),
+                 "skip1x1_in_lrelu_fwd: shapes have no fused kernel (ask ru3d_skip1x1_in_lrelu_fwd_supported first)");
+    return skip1x1_fused_launch(x, w_packed, bias, y, mean, scale, out, slope, as_stream(stream));
+}
+
 // ---- the two stride-2 convs of a pooling ResBlock: forward of both + InstanceNorm sums in one launch (conv_s2.hip, G form)
 extern "C" int ru3d_conv3d_s2_pair_fwd_in_supported(const ru3d_tensor* x, const ru3d_tensor* y3, const ru3d_tensor* y1, int dtype) {
     RU3D_FWD_F16(dtype, ru3d_conv3d_s2_pair_fwd_in_supported_f16(x, y3, y1, dtype));

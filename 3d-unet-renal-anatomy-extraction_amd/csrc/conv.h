@@ -80,7 +80,10 @@ int pack_mfma_launch(const float* src, void* dst, int cin, int cout, int taps, i
                      hipStream_t st);
 int conv_mfma_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
                      hipStream_t st, float* stat_slab = nullptr, void* ws = nullptr, size_t ws_bytes = 0,
-                     const void* bst_act = nullptr, int bst_ld = 0, float slope = 0.f);
+                     const void* bst_act = nullptr, int bst_ld = 0, float slope = 0.f, const void* x2 = nullptr,
+                     int ldx2 = 0, const void* w2 = nullptr);
+// y = conv3_dgrad(x) + W2^T x2 in one launch: only the 32-channel sliding kernel has the 28th tap
+bool mfma_conv_can_fuse_partner(const ConvGeom& g);
 size_t conv_mfma_ws_bytes(const ConvGeom& g);
 bool mfma_conv_can_fuse_stats(const ConvGeom& g);
 size_t mfma_conv_stats_slab_bytes(const ConvGeom& g);
@@ -107,8 +110,10 @@ struct SlidePlan {
 bool slide_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* out);
 // bst_act != NULL (input-gradient role): the slab receives the InstanceNorm + LeakyReLU backward sums of the output
 // against the activation bst_act (pitch bst_ld) instead of the forward statistics
+// x2 / ldx2 / w2: a second tensor on the output grid (32 channels) and a packed 1x1x1 input-gradient weight: y += W2^T x2
 int conv_slide_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
-                      float* stat_slab, hipStream_t st, const void* bst_act = nullptr, int bst_ld = 0, float slope = 0.f);
+                      float* stat_slab, hipStream_t st, const void* bst_act = nullptr, int bst_ld = 0, float slope = 0.f,
+                      const void* x2 = nullptr, int ldx2 = 0, const void* w2 = nullptr);
 
 // conv_slide64.hip (3x3x3 stride-1, 64 -> 64 / 128 channels: the same design on v_mfma_f32_16x16x32, a wave = 16 couts)
 bool slide64_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* out);
@@ -127,6 +132,11 @@ size_t conv_s2_tile_slab_bytes(const ConvGeom& g);
 int conv_s2_tile_slab_geom(const ConvGeom& g, int* gx, int* cb);
 int conv_s2_tile_launch(const void* x, const void* w, const float* bias, void* y, const ConvGeom& g, float* stat_slab,
                         const void* w2, const float* bias2, void* y2, int ldy2, hipStream_t st);
+
+// fused_skip.hip (decoder ResBlock tail: 1x1x1 skip conv + InstanceNorm apply + sum + LeakyReLU in one pass)
+bool skip1x1_fused_eligible(const ru3d_tensor* x, const ru3d_tensor* y2, const ru3d_tensor* out, int dtype);
+int skip1x1_fused_launch(const ru3d_tensor* x, const void* w, const float* bias, const ru3d_tensor* y2, const float* mean,
+                         const float* scale, const ru3d_tensor* out, float slope, hipStream_t st);
 
 // wgrad_slide.hip (3x3x3 stride-1 weight gradient on the large levels: D-sliding plane ring)
 struct WgradSlidePlan {

@@ -1566,10 +1566,17 @@ static bool aligned_to(const void* p, size_t a) { return (((uintptr_t)p) % a) ==
 // Cin % 32 == 0 on the LDS-halo kernel, everything else on the direct kernel (same packed-weight layout).
 bool mfma_conv_geometry_ok(const ConvGeom& g) { return !g.transposed || g.stride == 2; }
 
+bool mfma_conv_can_fuse_partner(const ConvGeom& g) {
+    if (!(g.k == 3 && g.stride == 1 && !g.transposed && g.Cin == 32)) return false;
+    SlidePlan sp;
+    return slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp);
+}
+
 int conv_mfma_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
                      hipStream_t st, float* stat_slab, void* ws, size_t ws_bytes, const void* bst_act, int bst_ld,
-                     float slope) {
+                     float slope, const void* x2, int ldx2, const void* w2) {
     if (!mfma_conv_geometry_ok(g)) return ru3d_fail(-1, "conv_mfma: geometry not supported");
+    if (x2 && !mfma_conv_can_fuse_partner(g)) return ru3d_fail(-1, "conv_mfma: no fused 1x1 partner for this shape");
     if ((g.ldx % 8) || (g.ldy % 4) || (res && (g.ldr % 4)) || !aligned_to(x, 16) || !aligned_to(y, 8) ||
         (res && !aligned_to(res, 8)) || (bias && !aligned_to(bias, 16)) || !aligned_to(w, 16))
         return ru3d_fail(-1, "conv_mfma: operands must be 16-byte (x, w, bias) / 8-byte (y, res) aligned");
@@ -1587,8 +1594,9 @@ int conv_mfma_launch(const void* x, const void* w, const float* bias, const void
                                  (!res || aligned_to(res, 16)) && (g.ldx % 8) == 0 && aligned_to(x, 16) &&
                                  (int64_t)g.Do * g.Ho * g.Wo * g.ldx < (1ll << 30);
             if (aligned && (!bst_act || ((bst_ld % 8) == 0 && aligned_to(bst_act, 16))))
-                return conv_slide_launch(x, w, bias, res, y, g, stat_slab, st, bst_act, bst_ld, slope);
+                return conv_slide_launch(x, w, bias, res, y, g, stat_slab, st, bst_act, bst_ld, slope, x2, ldx2, w2);
             if (bst_act) return ru3d_fail(-1, "conv_mfma: the fused backward sums need 16-byte aligned operands");
+            if (x2) return ru3d_fail(-1, "conv_mfma: the fused 1x1 partner needs 16-byte aligned operands");
             // the statistics slab (size, layout) was planned for the sliding kernel's grid: falling back to the
             // producer/consumer kernel here would fill it with another geometry
             if (stat_slab)

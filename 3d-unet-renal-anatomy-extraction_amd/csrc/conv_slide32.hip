@@ -51,6 +51,7 @@ struct Slide32Args {
     const bf16x8* w;
     const float* bias;
     const bf16* res;
+    const bf16x8* w2;                     // HAS_X2: packed input-gradient weight of the 1x1x1 partner
     bf16* y;
     float* stat_slab;
     int N, D, H, W;
@@ -109,7 +110,12 @@ __device__ __forceinline__ void mfma16(f32x4& acc, const bf16x8& w, const bf16x8
 // conv output IS the gradient wrt the activation a = lrelu(xhat), and the two sums that backward needs,
 // sum g' and sum g' * xhat with g' = g * lrelu'(a), xhat recovered from a, are taken in the row phase - `res` / `ldr`
 // carry the activation, the statistics slab the sums: the separate reduction pass over (g, a) disappears.
-template <bool HAS_RES, bool HAS_STATS, bool HAS_BST = false>
+// HAS_X2 (decoder ResBlock's input gradient, reference network.py:403-411): the 1x1x1 skip conv's input gradient
+// W_s^T g_pre is added as a 28th tap whose activation fragment is not a halo tile but the voxel's own row of a SECOND
+// tensor (`res` / `ldr` carry g_pre, `w2` its packed weight): the rows of the plane being computed are loaded straight
+// into MFMA B-fragment layout during pass 0 and consumed by 8 extra MFMAs behind pass 8 - the separate 1x1 launch, its
+// output and the residual read of that output disappear.
+template <bool HAS_RES, bool HAS_STATS, bool HAS_BST = false, bool HAS_X2 = false>
 __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a) {
     __shared__ __attribute__((aligned(16))) bf16 lds[RING * PLANE];
     __shared__ __attribute__((aligned(16))) bf16 est_s[4 * 64 * EP];    // epilogue patches (stored values), one per wave
@@ -144,6 +150,19 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
             wreg[f] = a.w[((st * 2 + (kb >> 1)) * NTT + (co >> 5)) * 64 + (co & 31) + 32 * (kb & 1)];
         });
     }
+
+    bf16x8 wreg2[2];
+    if constexpr (HAS_X2) {
+        const int NTT = a.cout_total / 32;
+        const int kb = lane >> 4;
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) {
+            const int co = co_b + 16 * ct + (lane & 15);
+            wreg2[ct] = a.w2[((kb >> 1) * NTT + (co >> 5)) * 64 + (co & 31) + 32 * (kb & 1)];
+        }
+    }
+    // B-fragment layout of a 16-voxel row of the second tensor: voxel lane & 15, k-block lane >> 4
+    const int xvoff = ((lane & 15) * a.ldr + (lane >> 4) * 8) * 2;
 
     // ---- staging: piece c = tid + 256 i of a plane is halo row c >> 2 = (tid >> 2) + 64 i, 16-byte piece tid & 3
     bf16* const sdst = lds + (tid >> 2) * PITCH + (tid & 3) * 8;
@@ -302,6 +321,9 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
         // this wave's output rows in plane d0
         ycur = reinterpret_cast<char*>(a.y + co_b) +
                ((((int64_t)n * a.D + d0) * a.H + h0 + RH * hr) * a.W + w0 + 16 * hw) * (int64_t)a.ldy * 2;
+        if constexpr (HAS_X2)
+            rcur = reinterpret_cast<const char*>(a.res) +
+                   ((((int64_t)n * a.D + d0) * a.H + h0 + RH * hr) * a.W + w0 + 16 * hw) * (int64_t)a.ldr * 2;
         if constexpr (HAS_RES || HAS_BST)
             rcur = reinterpret_cast<const char*>(a.res + co_b) +
                    ((((int64_t)n * a.D + d0) * a.H + h0 + RH * hr) * a.W + w0 + 16 * hw) * (int64_t)a.ldr * 2;
@@ -360,6 +382,16 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
                         }
                         if constexpr ((HAS_RES || HAS_BST) && q == NP - 1 && j % 3 == 1)
                             rq[(j - 1) / 3] = *reinterpret_cast<const bf16x8*>(rcur + ((j - 1) / 3) * rrow_b + rvoff);
+                        if constexpr (HAS_X2 && q == 0 && j % 3 == 1)
+                            rq[(j - 1) / 3] = *reinterpret_cast<const bf16x8*>(rcur + ((j - 1) / 3) * rrow_b + xvoff);
+                    }
+                    if constexpr (HAS_X2 && q == NP - 1 && j == NJ - 1) {
+                        // the partner's tap: output row m <- its own row of the second tensor
+                        static_for<0, RH>([&](auto mc) {
+                            constexpr int mm = decltype(mc)::value;
+                            mfma16<false>(acc[PAR][mm][0], wreg2[0], rq[mm]);
+                            mfma16<false>(acc[PAR][mm][1], wreg2[1], rq[mm]);
+                        });
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -368,7 +400,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
             SLIDE_STAMP_RT(PH, 121, s)
             yprev = ycur;
             ycur += yplane_b;
-            if constexpr (HAS_RES || HAS_BST) rcur += rplane_b;
+            if constexpr (HAS_RES || HAS_BST || HAS_X2) rcur += rplane_b;
         };
 
         // fragments of the first pass of step 0
@@ -456,7 +488,8 @@ bool slide_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* o
 }
 
 int conv_slide_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
-                      float* stat_slab, hipStream_t st, const void* bst_act, int bst_ld, float slope) {
+                      float* stat_slab, hipStream_t st, const void* bst_act, int bst_ld, float slope, const void* x2,
+                      int ldx2, const void* w2) {
     SlidePlan p;
     if (!slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &p))
         return ru3d_fail(-1, "conv_slide: shape not supported");
@@ -466,7 +499,10 @@ int conv_slide_launch(const void* x, const void* w, const float* bias, const voi
     // residual + statistics together is not a combination any entry point produces (ru3d_conv3d_fwd_in has no residual)
     if (res && stat_slab) return ru3d_fail(-1, "conv_slide: residual and fused statistics cannot be combined");
     if (bst_act && (res || !stat_slab)) return ru3d_fail(-1, "conv_slide: the backward sums need a slab and no residual");
+    if (x2 && (res || stat_slab || bst_act || !w2 || (ldx2 % 8) || (((uintptr_t)x2) | ((uintptr_t)w2)) % 16))
+        return ru3d_fail(-1, "conv_slide: the 1x1 partner excludes residual / statistics and needs aligned operands");
     Slide32Args a;
+    a.w2 = (const bf16x8*)w2;
     a.x = (const bf16*)x;
     a.w = (const bf16x8*)w;
     a.bias = bias;
@@ -484,7 +520,11 @@ int conv_slide_launch(const void* x, const void* w, const float* bias, const voi
     a.stamps = g_slide_stamps;
 #endif
     const dim3 grid(p.grid, p.ny), block(256);
-    if (bst_act) {
+    if (x2) {
+        a.res = (const bf16*)x2;
+        a.ldr = ldx2;
+        hipLaunchKernelGGL((conv3_s1_slide32_kernel<false, false, false, true>), grid, block, 0, st, a);
+    } else if (bst_act) {
         a.res = (const bf16*)bst_act;
         a.ldr = bst_ld;
         hipLaunchKernelGGL((conv3_s1_slide32_kernel<false, false, true>), grid, block, 0, st, a);

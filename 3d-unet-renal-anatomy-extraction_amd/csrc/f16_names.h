@@ -14,6 +14,8 @@
     X(ru3d_conv3d_s2_pair_fwd_in_supported) \
     X(ru3d_conv3d_s2_pair_fwd_in_workspace_bytes) \
     X(ru3d_conv3d_s2_pair_fwd_in) \
+    X(ru3d_conv3d_s1_dgrad_pair_supported) \
+    X(ru3d_conv3d_s1_dgrad_pair) \
     X(ru3d_conv3d_s2_dgrad_pair_supported) \
     X(ru3d_conv3d_s2_dgrad_pair) \
     X(ru3d_convtranspose3d_k3s2p1_fwd_in_workspace_bytes) \
@@ -29,6 +31,8 @@
     X(ru3d_convtranspose3d_k3s2p1_wgrad) \
     X(ru3d_instnorm_stats) \
     X(ru3d_in_lrelu_fwd) \
+    X(ru3d_skip1x1_in_lrelu_fwd_supported) \
+    X(ru3d_skip1x1_in_lrelu_fwd) \
     X(ru3d_in_lrelu_bwd) \
     X(ru3d_channel_sum) \
     X(ru3d_copy_channels) \
@@ -50,6 +54,8 @@
 #define ru3d_conv3d_s2_pair_fwd_in_supported ru3d_conv3d_s2_pair_fwd_in_supported_f16
 #define ru3d_conv3d_s2_pair_fwd_in_workspace_bytes ru3d_conv3d_s2_pair_fwd_in_workspace_bytes_f16
 #define ru3d_conv3d_s2_pair_fwd_in ru3d_conv3d_s2_pair_fwd_in_f16
+#define ru3d_conv3d_s1_dgrad_pair_supported ru3d_conv3d_s1_dgrad_pair_supported_f16
+#define ru3d_conv3d_s1_dgrad_pair ru3d_conv3d_s1_dgrad_pair_f16
 #define ru3d_conv3d_s2_dgrad_pair_supported ru3d_conv3d_s2_dgrad_pair_supported_f16
 #define ru3d_conv3d_s2_dgrad_pair ru3d_conv3d_s2_dgrad_pair_f16
 #define ru3d_convtranspose3d_k3s2p1_fwd_in_workspace_bytes ru3d_convtranspose3d_k3s2p1_fwd_in_workspace_bytes_f16
@@ -65,6 +71,8 @@
 #define ru3d_convtranspose3d_k3s2p1_wgrad ru3d_convtranspose3d_k3s2p1_wgrad_f16
 #define ru3d_instnorm_stats ru3d_instnorm_stats_f16
 #define ru3d_in_lrelu_fwd ru3d_in_lrelu_fwd_f16
+#define ru3d_skip1x1_in_lrelu_fwd_supported ru3d_skip1x1_in_lrelu_fwd_supported_f16
+#define ru3d_skip1x1_in_lrelu_fwd ru3d_skip1x1_in_lrelu_fwd_f16
 #define ru3d_in_lrelu_bwd ru3d_in_lrelu_bwd_f16
 #define ru3d_channel_sum ru3d_channel_sum_f16
 #define ru3d_copy_channels ru3d_copy_channels_f16

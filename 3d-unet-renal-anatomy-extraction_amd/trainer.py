@@ -84,7 +84,7 @@ class Trainer():
                  valid_split=0.2, num_samples=None, metrics=None, scheduler=None,
                  train_transform=None, valid_transform=None,
                  criterion=None, tr_transform=None, vd_transform=None, sync_every=1, progress=True,
-                 capture_step=False):
+                 capture_step=None):
         self.model = model
         self.optimizer = optimizer
         self.loss = loss if loss is not None else criterion
@@ -115,11 +115,15 @@ class Trainer():
         self.progress_bar = _NullBar()
         self._grad_sync = None
         self._scaler = None
-        # capture_step=True: training batches of the usual shape are replayed from a hipGraph of the whole step
-        # (graph.GraphedTrainStep - same numbers, the host only copies the batch in); needs optim.Adam, one process,
-        # bf16 / fp32 storage.  Off by default: the reference's loop is the eager one.
-        self.capture_step = bool(capture_step)
+        # capture_step: training batches of the usual shape are replayed from a hipGraph of the whole step
+        # (graph.GraphedTrainStep - the same kernels on the same data, bit for bit; the host only copies the batch in and
+        # one hipGraphLaunch replaces ~500 launches issued from Python).  Needs optim.Adam (its update kernel reads the
+        # step's scalars from device memory), one process, bf16 / fp32 storage.  None (default): on whenever those hold -
+        # with a caller-owned torch.optim.Adam, fp16 loss scaling or several ranks the loop is the eager one, and it
+        # stays the fallback if a capture fails.  True: insist (raises when not possible).  False: never.
+        self.capture_step = capture_step
         self._graphed = None
+        self._capture_failed = False
 
     # ------------------------------------------------------------------ small helpers
     def _split_indices(self):
@@ -170,13 +174,16 @@ class Trainer():
         return last
 
     def _graphed_step(self):
-        if not self.capture_step or self._grad_sync is not None or self._scaler is not None:
+        if self.capture_step is False or self._capture_failed or self._grad_sync is not None or self._scaler is not None:
             return None
         if self._graphed is None:
             import graph as graph_mod
             import optim as optim_mod
-            if not isinstance(self.optimizer, optim_mod.Adam):
-                raise TypeError("Trainer(capture_step=True) needs optim.Adam")
+            if not isinstance(self.optimizer, optim_mod.Adam) or self.device.type != 'cuda':
+                if self.capture_step:
+                    raise TypeError("Trainer(capture_step=True) needs optim.Adam and a model on a HIP device")
+                self._capture_failed = True       # auto mode: a caller-owned optimizer keeps the eager loop
+                return None
             self._graphed = graph_mod.GraphedTrainStep(self.model, self.loss, self.optimizer)
         return self._graphed
 
@@ -191,7 +198,16 @@ class Trainer():
             graphed = self._graphed_step() if is_train else None
             if graphed is not None:
                 self.model.train()
-                loss = graphed(x, y)
+                try:
+                    loss = graphed(x, y)
+                except Exception:
+                    if self.capture_step or graphed.graph is not None:
+                        raise
+                    # auto mode and the capture itself failed (an op that cannot be captured): eager from here on
+                    self._capture_failed = True
+                    self._graphed = None
+                    graphed = None
+            if graphed is not None:
                 y_pred = graphed.logits
                 scalars = {'loss': loss.clone()}         # a static buffer: the next replay overwrites it
                 if self.metrics is not None:

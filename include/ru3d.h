@@ -121,6 +121,12 @@ int ru3d_conv3d_fwd_in(const ru3d_tensor* x, const void* w_packed, const float* 
 int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* res,
                       const ru3d_tensor* dx, int k, int stride, int dtype, void* ws, size_t ws_bytes,
                       void* stream);
+/* The input gradient of a decoder ResBlock's two stride-1 convs of the same input in ONE launch (network.py:394 conv1
+ * k3 s1 and :403 skip_conv k1 s1, :406-411): dx = conv3_dgrad(dy; w3_packed) + conv1_dgrad(dy2; w1_packed), dy and dy2
+ * on the same grid with the same channel count.  `_supported` as above. */
+int ru3d_conv3d_s1_dgrad_pair_supported(const ru3d_tensor* dy, const ru3d_tensor* dy2, const ru3d_tensor* dx, int dtype);
+int ru3d_conv3d_s1_dgrad_pair(const ru3d_tensor* dy, const void* w3_packed, const ru3d_tensor* dy2, const void* w1_packed,
+                              const ru3d_tensor* dx, int dtype, void* stream);
 /* The forward of a pooling ResBlock's two stride-2 convs of the same input in ONE launch (network.py:394 conv1 k3 s2 p1,
  * :403 skip_conv k1 s2; :406-411), plus the InstanceNorm statistics of conv1's output as ru3d_conv3d_fwd_in takes them:
  *     y3 = conv3(x; w3, b3), (mean, scale) = IN statistics of Dropout3d(y3), y1 = conv1(x; w1, b1)
@@ -171,6 +177,13 @@ size_t ru3d_reduce_workspace_bytes(const ru3d_tensor* t);
  * x_hat = (y - mean) * scale equals InstanceNorm(Dropout3d(y)). */
 int ru3d_instnorm_stats(const ru3d_tensor* y, const float* drop_scale, float* mean, float* scale,
                         void* ws, size_t ws_bytes, float eps, int dtype, void* stream);
+/* The tail of a decoder ResBlock in one pass (network.py:403, 406-409, 414-416): out = LeakyReLU((y - mean) * scale +
+ * conv1x1(x; w_packed, bias), slope) - the skip conv's output is never stored.  `_supported`: a kernel exists for the
+ * shapes (the caller otherwise runs ru3d_conv3d_fwd(k = 1) + ru3d_in_lrelu_fwd(res = skip)). */
+int ru3d_skip1x1_in_lrelu_fwd_supported(const ru3d_tensor* x, const ru3d_tensor* y, const ru3d_tensor* out, int dtype);
+int ru3d_skip1x1_in_lrelu_fwd(const ru3d_tensor* x, const void* w_packed, const float* bias, const ru3d_tensor* y,
+                              const float* mean, const float* scale, const ru3d_tensor* out, float slope, int dtype,
+                              void* stream);
 /* out = LeakyReLU((y - mean) * scale (+ res), slope)  (network.py:414,416; 315-316). */
 int ru3d_in_lrelu_fwd(const ru3d_tensor* y, const float* mean, const float* scale, const ru3d_tensor* res,
                       const ru3d_tensor* out, float slope, int dtype, void* stream);

@@ -363,8 +363,9 @@ def test_g1_whole_net_bf16(golden_dir):
     (oracle.set_storage): every inter-kernel tensor and weight rounded to bf16, exact arithmetic inside
     each op.  The HIP path must be no worse than 1.3x that model's distance from the float64 truth (the
     two carry statistically equivalent rounding noise; measured 0.32-0.37 relative L2 on encoder weight
-    gradients for both), logits within 0.05 abs of the fp32 reference (measured 0.015), argmax flips only where the
-    reference's top-2 margin is below 0.05, loss within 2e-3."""
+    gradients for both), logits within 0.08 abs of the fp32 reference (measured 0.067 on this configuration, whose
+    storage model itself sits at 0.066; the benchmark model's 0.015 is gated at 0.05 in bench.py), argmax flips only
+    where the reference's top-2 margin is below 0.08, loss within 2e-3."""
     z, model = _g1_model(golden_dir)
     network.set_compute_dtype(model, torch.bfloat16)
     model.eval()
@@ -374,10 +375,10 @@ def test_g1_whole_net_bf16(golden_dir):
     assert logits.dtype == torch.float32
     ref = torch.from_numpy(z["logits"])
     got = logits.detach().cpu()
-    assert (got - ref).abs().max().item() <= 0.05
+    assert (got - ref).abs().max().item() <= 0.08
     margin = (ref[:, 0] - ref[:, 1]).abs()
     flips = got.argmax(1) != ref.argmax(1)
-    assert not (flips & (margin > 0.05)).any()
+    assert not (flips & (margin > 0.08)).any()
     assert flips.float().mean().item() < 0.02
     l = L.HybirdLoss()(logits, y)
     assert abs(l.item() - float(z["loss/hybird"])) <= 2e-3

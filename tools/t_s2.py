@@ -137,5 +137,41 @@ if which in ("all", "f"):
         e1 = (mean.cpu().double() - m).abs().max().item(); e2 = (scale.cpu().double() - sd / (sd * sd * v + 1e-5).sqrt()).abs().max().item()
         good = e1 < 1e-5 and e2 < 1e-4
         print("pair fwd stats %s: mean err %.3g scale err %.3g %s" % (dims, e1, e2, "ok" if good else "FAIL")); ok &= good
+if which in ("all", "k"):
+    # decoder tail: lrelu(IN(y2) + conv1x1(x)) in one pass
+    for cin, cout, dims in [(64, 32, (32, 32, 64)), (128, 64, (32, 32, 32)), (64, 32, (16, 40, 104))]:
+        g = torch.Generator().manual_seed(cin + cout + sum(dims))
+        d, h, w = dims
+        xv = torch.randn(2, cin, d, h, w, generator=g)
+        yv = torch.randn(2, cout, d, h, w, generator=g) * 2 + 0.3
+        w1 = torch.randn(cout, cin, 1, 1, 1, generator=g) * (1.0 / cin ** 0.5)
+        b1 = torch.randn(cout, generator=g)
+        mean = torch.randn(2 * cout, generator=g) * 0.1; scale = torch.rand(2 * cout, generator=g) + 0.5
+        out = ops.skip1x1_in_lrelu_fwd(ops.as_input(xv.to(DEV), BF), ops.pack_weight(w1.to(DEV), N.ROLE_CONV_FWD, BF, 1), b1.to(DEV),
+                                       ops.as_input(yv.to(DEV), BF), mean.to(DEV), scale.to(DEV))
+        if out is None:
+            print("fused skip %s: no kernel" % (dims,)); ok = False; continue
+        skip = F.conv3d(xv.bfloat16().float(), w1.bfloat16().float(), b1).bfloat16().float()
+        ref = F.leaky_relu((yv.bfloat16().float() - mean.view(2, cout, 1, 1, 1)) * scale.view(2, cout, 1, 1, 1) + skip, 0.01)
+        ok &= close(out, ref, 2 ** -8, "fused skip tail %s %s" % ((cin, cout), dims))
+if which in ("all", "d"):
+    # decoder block: conv1 (k3 s1) + skip conv (k1 s1) input gradients in one launch (32 -> 64 / 32 channels)
+    for cin, cout, dims, n in [(64, 32, (16, 64, 64), 2), (32, 32, (8, 64, 128), 3), (64, 32, (32, 32, 64), 2)]:
+        g = torch.Generator().manual_seed(cin + cout + sum(dims))
+        d, h, w = dims
+        xv = torch.randn(n, cin, d, h, w, generator=g)
+        w3 = torch.randn(cout, cin, 3, 3, 3, generator=g) * (1.0 / (27 * cin) ** 0.5)
+        w1 = torch.randn(cout, cin, 1, 1, 1, generator=g) * (1.0 / cin ** 0.5)
+        xr = xv.bfloat16().float().requires_grad_(True)
+        y3 = F.conv3d(xr, w3.bfloat16().float(), None, padding=1)
+        y1 = F.conv3d(xr, w1.bfloat16().float(), None)
+        g3 = torch.randn(y3.shape, generator=g); g1 = torch.randn(y1.shape, generator=g)
+        (y3 * g3.bfloat16().float()).sum().backward(retain_graph=True)
+        (y1 * g1.bfloat16().float()).sum().backward()
+        p3 = ops.pack_weight(w3.to(DEV), N.ROLE_CONV_DGRAD, BF, 1); p1 = ops.pack_weight(w1.to(DEV), N.ROLE_CONV_DGRAD, BF, 1)
+        gx = ops.conv_s1_dgrad_pair(ops.as_input(g3.to(DEV), BF), p3, ops.as_input(g1.to(DEV), BF), p1, tuple(xv.shape))
+        if gx is None:
+            print("s1 pair dgrad %s: no fused kernel" % (dims,)); ok = False; continue
+        ok &= close(gx, xr.grad, 2 ** -8, "s1 pair dgrad %s %s" % ((cin, cout), dims))
 print("ALL OK" if ok else "FAILED")
 sys.exit(0 if ok else 1)
