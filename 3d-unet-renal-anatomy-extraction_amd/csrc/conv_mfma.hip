@@ -1509,6 +1509,14 @@ static int launch_direct(const void* x, const void* w, const float* bias, const 
         nblk = (a.total + 255) / 256;
     }
     if (nblk > 0x7fffffff) return ru3d_fail(-1, "conv_direct_mfma: grid too large");
+    // (first: the fused entry points pick these kernels by the same test, and a block recomputed under activation
+    // checkpointing must get the same bits from the plain entry points)
+    // the large levels' stride-2 forms: LDS-DMA plane ring + producer wave + weights in registers (conv_s2.hip)
+    if (g.transposed && convt_s2_tile_eligible(g) &&
+        ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res)) % 16) == 0)
+        return convt_s2_tile_launch(x, w, bias, res, y, g, nullptr, nullptr, 0, nullptr, st);
+    if (!g.transposed && !res && conv_s2_tile_eligible(g) && (((uintptr_t)x) % 16) == 0 && (((uintptr_t)y) % 8) == 0)
+        return conv_s2_tile_launch(x, w, bias, y, g, nullptr, nullptr, nullptr, nullptr, 0, st);
     static const int ksplit_mode = getenv("RU3D_CONV_KSPLIT") ? atoi(getenv("RU3D_CONV_KSPLIT")) : 1;
     if (ksplit_mode && nblk * (g.Cout / (nt2 ? 64 : 32)) < 384) {
         // few, long workgroups: split the reduction over the waves of 32-voxel workgroups instead
@@ -1523,12 +1531,6 @@ static int launch_direct(const void* x, const void* w, const float* bias, const 
         }
         return ru3d_check_launch("conv_direct_ksplit");
     }
-    // the large levels' stride-2 forms: LDS-DMA plane ring + producer wave + weights in registers (conv_s2.hip)
-    if (g.transposed && convt_s2_tile_eligible(g) &&
-        ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)res)) % 16) == 0)
-        return convt_s2_tile_launch(x, w, bias, res, y, g, nullptr, nullptr, 0, nullptr, st);
-    if (!g.transposed && !res && conv_s2_tile_eligible(g) && (((uintptr_t)x) % 16) == 0 && (((uintptr_t)y) % 8) == 0)
-        return conv_s2_tile_launch(x, w, bias, y, g, nullptr, nullptr, nullptr, nullptr, 0, st);
     static const int tile_mode = getenv("RU3D_CONVT_TILE") ? atoi(getenv("RU3D_CONVT_TILE")) : 1;
     if (tile_mode && g.transposed && g.k == 3 && g.pad == 1) {
         // (TD+1)(TH+1)(TW+1) rows of Cin*2+16 bytes must fit in LDS: Cin <= 256 with the 16-wide tile, 128 with the 32-wide

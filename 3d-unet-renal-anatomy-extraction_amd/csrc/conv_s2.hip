@@ -207,9 +207,9 @@ __device__ __forceinline__ void t_consumer(const S2Args& a, const char* lds, con
                 s1 += __shfl_xor(s1, o, 64);
                 s2 += __shfl_xor(s2, o, 64);
             }
-            if (p == 0) {
-                dst[(8 * g4 + i) * 2] = s1;
-                dst[(8 * g4 + i) * 2 + 1] = s2;
+            if (p == 0) {      // += : the XCD-wise deal of units can bring a workgroup back to a sample (the slab starts at 0)
+                dst[(8 * g4 + i) * 2] += s1;
+                dst[(8 * g4 + i) * 2 + 1] += s2;
             }
             st1[i] = st2[i] = 0.f;
         }
@@ -572,9 +572,9 @@ __device__ __forceinline__ void g_consumer(const S2Args& a, const char* lds, int
                 s1 += __shfl_xor(s1, o, 64);
                 s2 += __shfl_xor(s2, o, 64);
             }
-            if (p == 0) {
-                dst[(16 * wave + 4 * g4 + i) * 2] = s1;
-                dst[(16 * wave + 4 * g4 + i) * 2 + 1] = s2;
+            if (p == 0) {      // += : see the T form
+                dst[(16 * wave + 4 * g4 + i) * 2] += s1;
+                dst[(16 * wave + 4 * g4 + i) * 2 + 1] += s2;
             }
             st1[i] = st2[i] = 0.f;
         }

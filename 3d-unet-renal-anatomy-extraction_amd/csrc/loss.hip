@@ -423,6 +423,10 @@ extern "C" int ru3d_adam_step(float* param, const float* grad, float* exp_avg, f
 __device__ __forceinline__ void adam_multi_body(const ru3d_adam_tensor* __restrict__ tensors,
                                                 const int32_t* __restrict__ block_map, int chunk_elems, float lr,
                                                 float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+    // no fused multiply-adds here: this body is compiled into two kernels (scalars as arguments / from device memory) and
+    // into a vector and a scalar path - left to the compiler, the contraction of b2 * v + (1 - b2) * g * g differed
+    // between them by one ulp, on the one parameter whose length is not a multiple of 4 (the head's bias)
+#pragma clang fp contract(off)
     const ru3d_adam_tensor t = tensors[block_map[2 * blockIdx.x]];
     if (!t.grad) return;
     const int64_t begin = (int64_t)block_map[2 * blockIdx.x + 1] * chunk_elems;

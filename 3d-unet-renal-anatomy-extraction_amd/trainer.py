@@ -119,8 +119,9 @@ class Trainer():
         # (graph.GraphedTrainStep - the same kernels on the same data, bit for bit; the host only copies the batch in and
         # one hipGraphLaunch replaces ~500 launches issued from Python).  Needs optim.Adam (its update kernel reads the
         # step's scalars from device memory), one process, bf16 / fp32 storage.  None (default): on whenever those hold -
-        # with a caller-owned torch.optim.Adam, fp16 loss scaling or several ranks the loop is the eager one, and it
-        # stays the fallback if a capture fails.  True: insist (raises when not possible).  False: never.
+        # with a caller-owned torch.optim.Adam, a loss that is not one of this package's fused losses (a user module may
+        # have host-side effects a replay would skip), fp16 loss scaling or several ranks the loop is the eager one, and
+        # it stays the fallback if a capture fails.  True: insist (raises when not possible).  False: never.
         self.capture_step = capture_step
         self._graphed = None
         self._capture_failed = False
@@ -183,6 +184,11 @@ class Trainer():
                 if self.capture_step:
                     raise TypeError("Trainer(capture_step=True) needs optim.Adam and a model on a HIP device")
                 self._capture_failed = True       # auto mode: a caller-owned optimizer keeps the eager loop
+                return None
+            if self.capture_step is None and not isinstance(self.loss, _loss_mod._FusedLoss):
+                # auto mode captures only what it knows to be free of host-side effects: a user-defined loss module (one
+                # that logs, counts, branches on values) must keep running every step
+                self._capture_failed = True
                 return None
             self._graphed = graph_mod.GraphedTrainStep(self.model, self.loss, self.optimizer)
         return self._graphed

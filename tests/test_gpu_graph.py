@@ -84,8 +84,8 @@ def test_graphed_training_equals_eager(dtype):
     else:
         same = torch.equal
         assert l_g == l_e, (l_g, l_e)
-    for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
-        assert same(a, b), k
+    bad = [k for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()) if not same(a, b)]
+    assert not bad, bad
     # the optimizer state interchanges with torch.optim.Adam's: step counts follow the replays
     sd_e, sd_g = o_e.state_dict(), o_g.state_dict()
     for k in sd_e["state"]:
@@ -143,9 +143,45 @@ def test_trainer_capture_step_equals_eager_fit():
         return tr, model
 
     tr_e, m_e = fit(False)
-    tr_g, m_g = fit(True)
-    assert tr_g._graphed is not None and tr_g._graphed.replays >= 3      # 3 epochs x (2 full batches + 1 short one)
-    assert tr_g._graphed.eager_steps >= 3
-    assert tr_e.best_result == tr_g.best_result
-    for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
-        assert torch.equal(a, b), k
+    assert tr_e._graphed is None
+    for capture in (True, None):          # None = the default: captured because optimizer and loss are this package's own
+        tr_g, m_g = fit(capture)
+        assert tr_g._graphed is not None and tr_g._graphed.replays >= 3      # 3 epochs x (2 full batches + 1 short one)
+        assert tr_g._graphed.eager_steps >= 3
+        assert tr_e.best_result == tr_g.best_result
+        for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+            assert torch.equal(a, b), k
+
+
+def test_trainer_default_keeps_the_eager_loop_for_foreign_optimizer_or_loss():
+    """capture_step=None: a caller-owned torch.optim.Adam, or a loss module that is not one of the package's fused
+    losses (it may have host-side effects a replay would skip), runs every step from Python as the reference does."""
+    import trainer as T
+
+    class Cases(torch.utils.data.Dataset):
+        def __len__(self):
+            return 2
+
+        def __getitem__(self, i):
+            return {"image": O.synth_image((1, 1, 32, 32, 32), 800 + i)[0], "label": O.phantom_labels(1, (32, 32, 32), 3)[0]}
+
+    class Counting(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.inner, self.calls = L.HybirdLoss(), 0
+
+        def forward(self, p, t):
+            self.calls += 1
+            return self.inner(p, t)
+
+    model, opt, _ = _setup(torch.bfloat16)
+    crit = Counting()
+    tr = T.Trainer(model=model, optimizer=opt, loss=crit, dataset=Cases(), batch_size=1, valid_split=0.0,
+                   dataloader_kwargs={"num_workers": 0}, progress=False)
+    tr.fit(num_epochs=4)
+    assert tr._graphed is None and crit.calls == 8
+    model, _, crit = _setup(torch.bfloat16)
+    tr = T.Trainer(model=model, optimizer=torch.optim.Adam(model.parameters(), lr=1e-4), loss=crit, dataset=Cases(),
+                   batch_size=1, valid_split=0.0, dataloader_kwargs={"num_workers": 0}, progress=False)
+    tr.fit(num_epochs=2)
+    assert tr._graphed is None
