@@ -114,7 +114,12 @@ SIGNATURES = {
     "ru3d_comm_unique_id": (_i, [_vp]),
     "ru3d_comm_init": (_i, [ctypes.POINTER(_vp), _vp, _i, _i, _i]),
     "ru3d_comm_allreduce": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    "ru3d_comm_reduce_scatter": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
+    "ru3d_comm_all_gather": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "ru3d_comm_available": (_i, []),
     "ru3d_comm_destroy": (_i, [_vp]),
+    "ru3d_set_cu_budget": (_i, [_i]),
+    "ru3d_get_cu_budget": (_i, []),
     "ru3d_flat_cast": (_i, [_vp, _i, _vp, _i, _i64, _f, _vp]),
 }
 COMM_ID_BYTES = 128

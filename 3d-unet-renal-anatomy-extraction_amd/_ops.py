@@ -270,9 +270,21 @@ def conv_dgrad_in_bwd(dy, pw, act, mean, scale, k=3, stride=1):
     return dyn
 
 
-def conv_wgrad(x, dy, k, stride):
+# parallel.GradSync: parameter storage address -> the fp32 slice of the exchange bucket its gradient will be sent from.
+# The weight-gradient kernels write there directly, so no copy into the bucket is needed (387 MB per step at config 2).
+GRAD_ARENA = {}
+
+
+def _grad_out(key, shape, device):
+    t = GRAD_ARENA.get(key) if key is not None else None
+    if t is not None and tuple(t.shape) == tuple(shape) and t.device == device:
+        return t.view(t.shape)      # a tensor object of its own: autograd adopts a gradient only when nobody else holds it
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+def conv_wgrad(x, dy, k, stride, key=None):
     cout, cin = dy.shape[1], x.shape[1]
-    dw = torch.empty((cout, cin, k, k, k), dtype=torch.float32, device=x.device)
+    dw = _grad_out(key, (cout, cin, k, k, k), x.device)
     dx, ddy = desc(x), desc(dy)
     code = N.dtype_code(x.dtype)
     nbytes = N.lib.ru3d_conv3d_wgrad_workspace_bytes(ref(dx), ref(ddy), k, stride, code)
@@ -372,9 +384,9 @@ def convt_dgrad(dy, pw, in_shape):
     return dx
 
 
-def convt_wgrad(x, dy):
+def convt_wgrad(x, dy, key=None):
     cin, cout = x.shape[1], dy.shape[1]
-    dw = torch.empty((cin, cout, 3, 3, 3), dtype=torch.float32, device=x.device)
+    dw = _grad_out(key, (cin, cout, 3, 3, 3), x.device)
     dx, ddy = desc(x), desc(dy)
     code = N.dtype_code(x.dtype)
     nbytes = N.lib.ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes(ref(dx), ref(ddy), code)
@@ -676,6 +688,7 @@ class ConvFn(torch.autograd.Function):
         ctx.stride, ctx.k, ctx.has_bias = stride, k, bias is not None
         ctx.storage_dtype = storage_dtype
         ctx.in_dtype = x.dtype
+        ctx.wkey = weight.data_ptr() if not (cout_seg or cin_seg) else None
         return y
 
     @staticmethod
@@ -687,7 +700,7 @@ class ConvFn(torch.autograd.Function):
         gx = gw = gb = None
         with _OnSide(gy.device):
             if ctx.needs_input_grad[1]:
-                gw = unpad_wgrad(conv_wgrad(xin, gy, ctx.k, ctx.stride), cout, cin, cout_seg, cin_seg)
+                gw = unpad_wgrad(conv_wgrad(xin, gy, ctx.k, ctx.stride, key=ctx.wkey), cout, cin, cout_seg, cin_seg)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 gb = channel_sum(gy)[:cout]
         if ctx.needs_input_grad[0]:
@@ -780,6 +793,9 @@ class ResBlockFn(torch.autograd.Function):
                                   None, None, None, None)
         ctx.dims = (cout, cin, cout_seg, cin_seg)
         ctx.stride = stride
+        plain = not (cout_seg or cin_seg)
+        ctx.wkeys = (w1.data_ptr() if plain else None, w2.data_ptr() if plain else None,
+                     ws.data_ptr() if (plain and ws is not None) else None)
         ctx.has_skip_conv = ws is not None
         ctx.in_link = in_link if (in_link is not None and ws is not None) else None
         if in_link is not None:
@@ -805,9 +821,9 @@ class ResBlockFn(torch.autograd.Function):
         del y2
         gws = gbs = None
         with _OnSide(dev):
-            gw2 = unpad_wgrad(conv_wgrad(a1, dy2, 3, 1), cout, cout, cout_seg, cout_seg)
+            gw2 = unpad_wgrad(conv_wgrad(a1, dy2, 3, 1, key=ctx.wkeys[1]), cout, cout, cout_seg, cout_seg)
             if ctx.has_skip_conv:
-                gws = unpad_wgrad(conv_wgrad(x, gpre, 1, stride), cout, cin, cout_seg, cin_seg)
+                gws = unpad_wgrad(conv_wgrad(x, gpre, 1, stride, key=ctx.wkeys[2]), cout, cin, cout_seg, cin_seg)
                 gbs = gbs_sum[:cout]
         gb2 = None   # a bias that feeds InstanceNorm has an identically zero gradient: reported as "no gradient"
         # conv2's input gradient and the IN1 + LeakyReLU backward in one call: on the sliding-kernel shapes the backward's
@@ -815,7 +831,7 @@ class ResBlockFn(torch.autograd.Function):
         dy1 = conv_dgrad_in_bwd(dy2, pw2d, a1, mean1, scale1)
         del dy2, a1, y1
         with _OnSide(dev):
-            gw1 = unpad_wgrad(conv_wgrad(x, dy1, 3, stride), cout, cin, cout_seg, cin_seg)
+            gw1 = unpad_wgrad(conv_wgrad(x, dy1, 3, stride, key=ctx.wkeys[0]), cout, cin, cout_seg, cin_seg)
         gb1 = None
         gx = None
         need_gx = ctx.needs_input_grad[0]
@@ -887,6 +903,7 @@ class UpFn(torch.autograd.Function):
         ctx.save_for_backward(x, y, out, mean, scale, packs[1] if ctx.needs_input_grad[0] else None)
         ctx.dims = (cout, cin, cout_seg, cin_seg)
         ctx.has_skip = skip is not None
+        ctx.wkey = wt.data_ptr() if not (cout_seg or cin_seg) else None
         ctx.link = link if (link is not None and getattr(link, "fused_grad", False)) else None
         return out
 
@@ -903,7 +920,7 @@ class UpFn(torch.autograd.Function):
         dy, _ = in_lrelu_bwd(gu, u, y, mean, scale, zero_far=True)
         with _OnSide(x.device):
             # the ConvTranspose3d weight is [Cin][Cout][27]: its outer dimension is the module's in_channels
-            gw = unpad_wgrad(convt_wgrad(x, dy), cin, cout, cin_seg, cout_seg)
+            gw = unpad_wgrad(convt_wgrad(x, dy, key=ctx.wkey), cin, cout, cin_seg, cout_seg)
             gb = channel_sum(dy)[:cout]
         gx = None
         if ctx.needs_input_grad[0]:

@@ -27,6 +27,8 @@ struct Rccl {
     int (*CommInitRank)(nccl_comm_t*, int, nccl_unique_id, int) = nullptr;
     int (*CommDestroy)(nccl_comm_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, nccl_comm_t, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, nccl_comm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     const char* (*GetLastError)(nccl_comm_t) = nullptr;
     bool ok = false;
@@ -63,6 +65,8 @@ void load_rccl() {
     RU3D_SYM(CommInitRank, "ncclCommInitRank")
     RU3D_SYM(CommDestroy, "ncclCommDestroy")
     RU3D_SYM(AllReduce, "ncclAllReduce")
+    RU3D_SYM(ReduceScatter, "ncclReduceScatter")
+    RU3D_SYM(AllGather, "ncclAllGather")
     RU3D_SYM(GetErrorString, "ncclGetErrorString")
 #undef RU3D_SYM
     g_rccl.GetLastError = (decltype(g_rccl.GetLastError))dlsym(h, "ncclGetLastError");   // optional
@@ -176,6 +180,61 @@ extern "C" int ru3d_comm_allreduce(void* comm, void* buf, int64_t count, int dty
     if (rc != NCCL_SUCCESS) return rccl_fail("comm_allreduce", rc, h->comm);
     return 0;
 }
+
+// in place as RCCL defines it: the reduce-scatter's receive buffer is the rank's own shard of the send buffer, the
+// all-gather's send buffer the rank's own shard of the receive buffer
+extern "C" int ru3d_comm_reduce_scatter(void* comm, void* buf, int64_t count_per_rank, int dtype, int average, void* stream) {
+    RU3D_REQUIRE(comm && buf && count_per_rank > 0, "comm_reduce_scatter: bad argument");
+    RU3D_REQUIRE(dtype == RU3D_F32 || dtype == RU3D_BF16, "comm_reduce_scatter: dtype must be f32 or bf16");
+    Comm* h = (Comm*)comm;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != h->device) {
+        hipError_t e = hipSetDevice(h->device);
+        if (e != hipSuccess) return ru3d_fail((int)e, "comm_reduce_scatter: hipSetDevice: %s", hipGetErrorString(e));
+    }
+    const size_t esz = dtype == RU3D_F32 ? 4 : 2;
+    char* mine = (char*)buf + (size_t)h->rank * (size_t)count_per_rank * esz;
+    int rc = g_rccl.ReduceScatter(buf, mine, (size_t)count_per_rank, dtype == RU3D_F32 ? NCCL_FLOAT32 : NCCL_BFLOAT16,
+                                  average ? NCCL_AVG : NCCL_SUM, h->comm, as_stream(stream));
+    if (cur != h->device && cur >= 0) (void)hipSetDevice(cur);
+    if (rc != NCCL_SUCCESS) return rccl_fail("comm_reduce_scatter", rc, h->comm);
+    return 0;
+}
+
+extern "C" int ru3d_comm_all_gather(void* comm, void* buf, int64_t count_per_rank, int dtype, void* stream) {
+    RU3D_REQUIRE(comm && buf && count_per_rank > 0, "comm_all_gather: bad argument");
+    RU3D_REQUIRE(dtype == RU3D_F32 || dtype == RU3D_BF16, "comm_all_gather: dtype must be f32 or bf16");
+    Comm* h = (Comm*)comm;
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != h->device) {
+        hipError_t e = hipSetDevice(h->device);
+        if (e != hipSuccess) return ru3d_fail((int)e, "comm_all_gather: hipSetDevice: %s", hipGetErrorString(e));
+    }
+    const size_t esz = dtype == RU3D_F32 ? 4 : 2;
+    const char* mine = (const char*)buf + (size_t)h->rank * (size_t)count_per_rank * esz;
+    int rc = g_rccl.AllGather(mine, buf, (size_t)count_per_rank, dtype == RU3D_F32 ? NCCL_FLOAT32 : NCCL_BFLOAT16, h->comm,
+                              as_stream(stream));
+    if (cur != h->device && cur >= 0) (void)hipSetDevice(cur);
+    if (rc != NCCL_SUCCESS) return rccl_fail("comm_all_gather", rc, h->comm);
+    return 0;
+}
+
+extern "C" int ru3d_comm_available(void) {
+    std::call_once(g_rccl_once, load_rccl);
+    if (!g_rccl.ok) ru3d_fail(-2, "comm_available: %s", g_rccl.why.c_str());
+    return g_rccl.ok ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- CU budget of the persistent kernels
+static int g_cu_budget = 0;
+extern "C" int ru3d_set_cu_budget(int cus) {
+    RU3D_REQUIRE(cus >= 0 && cus <= 1024, "set_cu_budget: %d", cus);
+    g_cu_budget = cus;
+    return 0;
+}
+extern "C" int ru3d_get_cu_budget(void) { return g_cu_budget > 0 ? g_cu_budget : 256; }
 
 extern "C" int ru3d_comm_destroy(void* comm) {
     if (!comm) return 0;

@@ -746,7 +746,7 @@ static bool t_plan(int N, int Di, int Hi, int Wi, int Cin, int Cout, int* tw_out
             const int dl = (Di + ds - 1) / ds;
             if ((int64_t)dl * (ds - 1) >= Di) continue;          // an empty last chunk
             const int64_t units = cols * ds;
-            int64_t gx = 256 / ny;
+            int64_t gx = ru3d_get_cu_budget() / ny;
             if (gx > units) gx = units;
             // a step of the wide tile moves twice the voxels of a narrow one
             const int64_t cost = ((units + gx - 1) / gx) * (int64_t)(dl + 2) * tw;
@@ -766,7 +766,7 @@ static bool t_plan(int N, int Di, int Hi, int Wi, int Cin, int Cout, int* tw_out
     out->tiles_h = (Hi + TH - 1) / TH;
     out->tiles_w = (Wi + best_tw - 1) / best_tw;
     out->units = (int)units;
-    int g = units < 256 / ny ? (int)units : 256 / ny;
+    int g = units < ru3d_get_cu_budget() / ny ? (int)units : ru3d_get_cu_budget() / ny;
     if ((units % 8) == 0 && g >= 8) g = (g / 8) * 8;
     out->grid = g;
     out->ny = ny;
@@ -872,7 +872,7 @@ static bool g_plan(int N, int Do, int Ho, int Wo, int Cin, int Cout, SlidePlan* 
         const int dl = (Do + ds - 1) / ds;
         if ((int64_t)dl * (ds - 1) >= Do) continue;
         const int64_t units = cols * ds;
-        int64_t gx = 256 / ny;
+        int64_t gx = ru3d_get_cu_budget() / ny;
         if (gx > units) gx = units;
         const int64_t cost = ((units + gx - 1) / gx) * (int64_t)(2 * dl + 3);      // planes through a workgroup
         if (best_cost < 0 || cost < best_cost) {
@@ -888,7 +888,7 @@ static bool g_plan(int N, int Do, int Ho, int Wo, int Cin, int Cout, SlidePlan* 
     out->tiles_h = (Ho + TH - 1) / TH;
     out->tiles_w = (Wo + GW - 1) / GW;
     out->units = (int)units;
-    int g = units < 256 / ny ? (int)units : 256 / ny;
+    int g = units < ru3d_get_cu_budget() / ny ? (int)units : ru3d_get_cu_budget() / ny;
     if ((units % 8) == 0 && g >= 8) g = (g / 8) * 8;
     out->grid = g;
     out->ny = ny;

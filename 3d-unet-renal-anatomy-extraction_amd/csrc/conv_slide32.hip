@@ -462,7 +462,7 @@ bool slide_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* o
         const int64_t units = cols * ds;
         if (units * ny > 0x7fffffff) break;
         // grid.x = min(units, 256 / ny rounded to 8) persistent workgroups per slice
-        int64_t gx = 256 / ny;
+        int64_t gx = ru3d_get_cu_budget() / ny;
         if (gx > units) gx = units;
         const int64_t cost = ((units + gx - 1) / gx) * (dl + 3);
         if (best_cost < 0 || cost < best_cost) {
@@ -473,14 +473,14 @@ bool slide_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* o
     if (!best) return false;
     const int64_t units = cols * best;
     // worth it only when the 256 CUs are reasonably filled
-    const double ideal = (double)cols * ny * D / 256.0;
+    const double ideal = (double)cols * ny * D / (double)ru3d_get_cu_budget();
     if (units * ny < 128 || (double)best_cost > 1.6 * ideal + 8) return false;
     out->dsplit = best;
     out->DL = D / best;
     out->tiles_h = H / TH;
     out->tiles_w = W / TW;
     out->units = (int)units;
-    int g = units < 256 / ny ? (int)units : 256 / ny;
+    int g = units < ru3d_get_cu_budget() / ny ? (int)units : ru3d_get_cu_budget() / ny;
     if ((units % 8) == 0 && g >= 8) g = (g / 8) * 8;
     out->grid = g;
     out->ny = ny;

@@ -375,7 +375,7 @@ bool slide64_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan*
         if (dl % 4) continue;
         const int64_t units = cols * ds;
         if (units * ny > 0x7fffffff) break;
-        int64_t gx = 256 / ny;
+        int64_t gx = ru3d_get_cu_budget() / ny;
         if (gx > units) gx = units;
         const int64_t cost = ((units + gx - 1) / gx) * (dl + 4);
         if (best_cost < 0 || cost < best_cost) {
@@ -385,14 +385,14 @@ bool slide64_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan*
     }
     if (!best) return false;
     const int64_t units = cols * best;
-    const double ideal = (double)cols * ny * D / 256.0;
+    const double ideal = (double)cols * ny * D / (double)ru3d_get_cu_budget();
     if (units * ny < 128 || (double)best_cost > 1.7 * ideal + 8) return false;
     out->dsplit = best;
     out->DL = D / best;
     out->tiles_h = H / TH;
     out->tiles_w = W / TW;
     out->units = (int)units;
-    int g = units < 256 / ny ? (int)units : 256 / ny;
+    int g = units < ru3d_get_cu_budget() / ny ? (int)units : ru3d_get_cu_budget() / ny;
     if ((units % 8) == 0 && g >= 8) g = (g / 8) * 8;
     out->grid = g;
     out->ny = ny;

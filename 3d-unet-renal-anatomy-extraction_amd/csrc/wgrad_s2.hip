@@ -317,7 +317,7 @@ static int s2_tw(const WgradGeom& g) { return s2_dma(g) ? DW : TWO; }
 
 static int s2_groups(const WgradGeom& g, int64_t ntiles) {
     const int pairs = (g.Cin / 32) * (g.Cout / (32 * s2_nco(g)));
-    int64_t G = 256 / pairs;            // one workgroup per CU (112-123 KB of LDS each)
+    int64_t G = ru3d_get_cu_budget() / pairs;            // one workgroup per CU (112-123 KB of LDS each)
     if (G < 1) G = 1;
     if (G > ntiles) G = ntiles;
     return (int)G;

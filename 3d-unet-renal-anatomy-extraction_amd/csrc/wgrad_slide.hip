@@ -238,7 +238,7 @@ bool wgrad_slide_plan(const WgradGeom& g, WgradSlidePlan* out) {
     const int pairs = (g.Cin / 32) * (g.Cout / 32);
     if (pairs > 8) return false;
     const int64_t cols = (int64_t)g.N * (g.Ho / TH) * (g.Wo / TW);
-    const int gmax = 256 / pairs;             // one workgroup per CU in total
+    const int gmax = ru3d_get_cu_budget() / pairs;             // one workgroup per CU in total
     int64_t best_cost = -1;
     int best = 0;
     for (int ds = 1; ds <= g.Do / 8; ds++) {
@@ -255,7 +255,7 @@ bool wgrad_slide_plan(const WgradGeom& g, WgradSlidePlan* out) {
     }
     if (!best) return false;
     const int64_t units = cols * best;
-    const double ideal = (double)cols * pairs * g.Do / 256.0;
+    const double ideal = (double)cols * pairs * g.Do / (double)ru3d_get_cu_budget();
     if (units * pairs < 192 || (double)best_cost > 1.5 * ideal + 8) return false;
     out->dsplit = best;
     out->DL = g.Do / best;

@@ -17,7 +17,16 @@ Design (MI355X: 7 xGMI links per GPU, point-to-point):
     RCCL's reduction and the result is widened back into the fp32 bucket the gradients alias);
   * transport "torch": `torch.distributed.all_reduce` (gloo on CPU tensors for the world_size-2 tests, or the
     process group's own nccl backend);
-  * after the exchange `param.grad` aliases its slice of the fp32 bucket (no copy-out);
+  * after the exchange `param.grad` aliases its slice of the fp32 bucket (no copy-out), and from the second step on the
+    weight-gradient kernels WRITE into that slice (`_ops.GRAD_ARENA`, filled in `begin_step` from the previous step's
+    layout): no copy-in either - only the few small gradients that do not come from a weight-gradient kernel (biases)
+    are copied;
+  * `exchange="rs_ag"`: reduce-scatter + all-gather (`ru3d_comm_reduce_scatter` / `_all_gather`) instead of one
+    all-reduce - the form SURVEY 8(e) asks for on point-to-point xGMI; same result;
+  * `reserve_cus=n` (default 16 when world > 1, RU3D_RESERVE_CUS): the persistent conv kernels size their grids for the
+    device's CUs minus n (`ru3d_set_cu_budget`), so RCCL's reduction kernels on the side stream find free CUs;
+  * every rank must end up on the same transport: `negotiate_transport` votes (MIN over ranks of "librccl loads
+    here") before any rank enters the collective communicator set-up, and a failed set-up is voted on again;
   * parameters that never receive a gradient (the unused skip_conv of same-shape ResBlocks, reference
     network.py:403-409) are left out identically on every rank.
 """
@@ -38,6 +47,7 @@ class RcclComm:
         self.N = N
         self.world, self.rank = world, rank
         self.device = torch.device(device)
+        self.handle = None
         blob = (ctypes.c_char * N.COMM_ID_BYTES)()
         key = "ru3d_comm_id_%d" % _COMM_SEQ[0]
         _COMM_SEQ[0] += 1
@@ -45,10 +55,17 @@ class RcclComm:
             if store is None:
                 store = dist.distributed_c10d._get_default_store()
             if rank == 0:
-                N.check(N.lib.ru3d_comm_unique_id(ctypes.cast(blob, ctypes.c_void_p)), "comm_unique_id")
+                try:
+                    N.check(N.lib.ru3d_comm_unique_id(ctypes.cast(blob, ctypes.c_void_p)), "comm_unique_id")
+                except Exception:
+                    store.set(key, b"FAIL")          # peers must not wait for an id that will never come
+                    raise
                 store.set(key, bytes(blob.raw))
             else:
-                blob.raw = bytes(store.get(key))[:N.COMM_ID_BYTES]
+                got = bytes(store.get(key))
+                if got == b"FAIL":
+                    raise N.Ru3dError("RcclComm: rank 0 could not create the communicator id")
+                blob.raw = got[:N.COMM_ID_BYTES]
         else:
             N.check(N.lib.ru3d_comm_unique_id(ctypes.cast(blob, ctypes.c_void_p)), "comm_unique_id")
         handle = ctypes.c_void_p()
@@ -63,14 +80,71 @@ class RcclComm:
                                           N.dtype_code(flat.dtype), 1 if average else 0,
                                           ctypes.c_void_p(stream.cuda_stream)), "comm_allreduce")
 
+    def reduce_scatter(self, flat, per_rank, average, stream):
+        N = self.N
+        N.check(N.lib.ru3d_comm_reduce_scatter(self.handle, ctypes.c_void_p(flat.data_ptr()), per_rank,
+                                               N.dtype_code(flat.dtype), 1 if average else 0,
+                                               ctypes.c_void_p(stream.cuda_stream)), "comm_reduce_scatter")
+
+    def all_gather(self, flat, per_rank, stream):
+        N = self.N
+        N.check(N.lib.ru3d_comm_all_gather(self.handle, ctypes.c_void_p(flat.data_ptr()), per_rank,
+                                           N.dtype_code(flat.dtype), ctypes.c_void_p(stream.cuda_stream)), "comm_all_gather")
+
     def destroy(self):
         if self.handle is not None and self.handle.value:
             self.N.lib.ru3d_comm_destroy(self.handle)
         self.handle = None
 
 
+def _vote(ok, group=None):
+    """MIN over ranks of a 0 / 1 flag (CPU tensor on gloo, device tensor otherwise)."""
+    backend = dist.get_backend(group)
+    dev = "cpu" if backend == "gloo" else torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
+def negotiate_transport(want="rccl", process_group=None):
+    """The transport EVERY rank will use: 'rccl' only when librccl loads on all of them (asked before any rank enters
+    the collective communicator set-up - a rank that fell back alone would leave its peers waiting in it)."""
+    if want != "rccl":
+        return "torch"
+    ok = False
+    try:
+        import _native as N
+        ok = bool(N.lib.ru3d_comm_available())
+    except Exception:
+        ok = False
+    return "rccl" if _vote(ok, process_group) else "torch"
+
+
+def make_grad_sync(module, transport="rccl", process_group=None, **kwargs):
+    """GradSync on a transport all ranks agree on: vote, build, vote on the outcome, fall back together."""
+    transport = negotiate_transport(transport, process_group)
+    sync, err = None, None
+    if transport == "rccl":
+        try:
+            sync = GradSync(module, transport="rccl", process_group=process_group, **kwargs)
+        except Exception as e:      # noqa: BLE001 - reported below, after the vote
+            err = e
+        if not _vote(sync is not None, process_group):
+            if sync is not None:
+                sync.remove()       # hooks and communicator of the half-built job
+            sync = None
+            transport = "torch"
+    if sync is None:
+        kwargs.pop("grad_dtype", None)
+        kwargs.pop("exchange", None)
+        sync = GradSync(module, transport="torch", process_group=process_group, **kwargs)
+    sync.fallback_reason = repr(err) if err is not None else None
+    return sync
+
+
 class GradSync:
-    def __init__(self, module, bucket_bytes=64 << 20, process_group=None, transport=None, grad_dtype=None, comm=None):
+    def __init__(self, module, bucket_bytes=64 << 20, process_group=None, transport=None, grad_dtype=None, comm=None,
+                 exchange=None, reserve_cus=None):
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group)
@@ -101,18 +175,39 @@ class GradSync:
         if grad_dtype == torch.bfloat16 and transport != "rccl":
             raise ValueError("bf16 gradient transport needs the 'rccl' transport")
         self.grad_dtype = grad_dtype
+        if exchange is None:
+            exchange = os.environ.get("RU3D_EXCHANGE", "allreduce")
+        if exchange not in ("allreduce", "rs_ag"):
+            raise ValueError("GradSync exchange must be 'allreduce' or 'rs_ag'")
+        if exchange == "rs_ag" and transport != "rccl":
+            raise ValueError("the reduce-scatter + all-gather exchange needs the 'rccl' transport")
+        self.exchange = exchange
         self.comm = None
         self._owns_comm = False
         self._side = None
+        self._prev_layout = {}    # parameter storage address -> (bucket index, offset, numel) of the previous step
+        self._reserved = 0
         if transport == "rccl":
             dev = self.params[0].device
             self.comm = comm
             if comm is None:
                 if process_group is not None:
+                    self.remove()
                     raise ValueError("GradSync(transport='rccl') on a sub-group needs an explicit RcclComm")
-                self.comm = RcclComm(self.world, self.rank, dev)
+                try:
+                    self.comm = RcclComm(self.world, self.rank, dev)
+                except Exception:
+                    self.remove()     # do not leave the hooks of a half-built exchange on the parameters
+                    raise
                 self._owns_comm = True
             self._side = torch.cuda.Stream(device=dev)
+            if reserve_cus is None:
+                reserve_cus = int(os.environ.get("RU3D_RESERVE_CUS", "16" if self.world > 1 else "0"))
+            if reserve_cus > 0:
+                N = self.comm.N
+                total = torch.cuda.get_device_properties(dev).multi_processor_count
+                N.check(N.lib.ru3d_set_cu_budget(max(8, total - int(reserve_cus))), "set_cu_budget")
+                self._reserved = int(reserve_cus)
         backend = dist.get_backend(process_group)
         self._avg_op = dist.ReduceOp.AVG if backend == "nccl" else None
 
@@ -121,6 +216,21 @@ class GradSync:
         self._fill, self._fill_elems, self._bucket_idx = [], 0, 0
         self._inflight = []
         self._active = True
+        self.copied_elems = self.inplace_elems = 0      # this step: gradient elements copied into / born inside a bucket
+        # gradients are born inside the buckets: the slice a parameter had in the previous step's layout is offered to the
+        # weight-gradient kernels as their output (parameters accumulating into an existing .grad keep the copy path)
+        try:
+            import _ops
+        except ImportError:
+            return
+        _ops.GRAD_ARENA.clear()
+        for p in self.params:
+            slot = self._prev_layout.get(p.data_ptr())
+            if slot is None or p.grad is not None:
+                continue
+            bi, off, n = slot
+            if bi < len(self._buckets) and n == p.numel() and self._buckets[bi].device == p.device:
+                _ops.GRAD_ARENA[p.data_ptr()] = self._buckets[bi][off:off + n].view_as(p)
 
     def _on_grad(self, param):
         if not self._active or param.grad is None:
@@ -155,16 +265,26 @@ class GradSync:
             return
         params, self._fill = self._fill, []
         elems, self._fill_elems = self._fill_elems, 0
-        idx, full = self._flat(elems, params[0].grad)
+        pad = (-elems) % self.world if self.exchange == "rs_ag" else 0
+        idx, full = self._flat(elems + pad, params[0].grad)
         flat = full[:elems]
         layout, off = [], 0
-        views = []
+        views, srcs = [], []
         for p in params:
             n = p.numel()
-            views.append(flat[off:off + n].view_as(p.grad))
+            v = flat[off:off + n].view_as(p.grad)
+            if p.grad.data_ptr() != v.data_ptr():      # not born in place (first step, biases, a changed order)
+                views.append(v)
+                srcs.append(p.grad)
             layout.append((p, off, n))
+            self._prev_layout[p.data_ptr()] = (idx, off, n)
             off += n
-        torch._foreach_copy_(views, [p.grad for p in params])      # copy-in (main stream)
+        self.copied_elems += sum(v.numel() for v in views)
+        self.inplace_elems += elems - sum(v.numel() for v in views)
+        if views:
+            torch._foreach_copy_(views, srcs)          # copy-in (main stream)
+        if pad:
+            full[elems:elems + pad].zero_()
         work = None
         if self.transport == "rccl":
             N = self.comm.N
@@ -172,12 +292,21 @@ class GradSync:
             self._side.wait_stream(main)
             side = ctypes.c_void_p(self._side.cuda_stream)
             if self.grad_dtype == torch.bfloat16:
-                wire = self._wire_buf(idx, elems, flat.device)[:elems]
-                N.check(N.lib.ru3d_flat_cast(ctypes.c_void_p(flat.data_ptr()), N.F32, ctypes.c_void_p(wire.data_ptr()),
-                                             N.BF16, elems, 1.0, side), "flat_cast")
-                self.comm.allreduce(wire, True, self._side)
-                N.check(N.lib.ru3d_flat_cast(ctypes.c_void_p(wire.data_ptr()), N.BF16, ctypes.c_void_p(flat.data_ptr()),
-                                             N.F32, elems, 1.0, side), "flat_cast")
+                wire = self._wire_buf(idx, elems + pad, flat.device)[:elems + pad]
+                N.check(N.lib.ru3d_flat_cast(ctypes.c_void_p(full.data_ptr()), N.F32, ctypes.c_void_p(wire.data_ptr()),
+                                             N.BF16, elems + pad, 1.0, side), "flat_cast")
+                if self.exchange == "rs_ag":
+                    per = (elems + pad) // self.world
+                    self.comm.reduce_scatter(wire, per, True, self._side)
+                    self.comm.all_gather(wire, per, self._side)
+                else:
+                    self.comm.allreduce(wire, True, self._side)
+                N.check(N.lib.ru3d_flat_cast(ctypes.c_void_p(wire.data_ptr()), N.BF16, ctypes.c_void_p(full.data_ptr()),
+                                             N.F32, elems + pad, 1.0, side), "flat_cast")
+            elif self.exchange == "rs_ag":
+                per = (elems + pad) // self.world
+                self.comm.reduce_scatter(full[:elems + pad], per, True, self._side)
+                self.comm.all_gather(full[:elems + pad], per, self._side)
             else:
                 self.comm.allreduce(flat, True, self._side)
         elif self._avg_op is not None:
@@ -185,6 +314,16 @@ class GradSync:
         else:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._inflight.append((work, flat, layout))
+        # bucket idx is on its way: nothing may be born in it any more (a parameter whose gradient arrives later than it
+        # did in the previous step keeps the copy path)
+        if self._prev_layout:
+            try:
+                import _ops
+                stale = [k for k in _ops.GRAD_ARENA if self._prev_layout.get(k, (None,))[0] == idx]
+                for k in stale:
+                    del _ops.GRAD_ARENA[k]
+            except ImportError:
+                pass
 
     def finish_step(self):
         """Flush the last partial bucket, wait for every exchange, alias grads to the reduced buckets."""
@@ -202,10 +341,18 @@ class GradSync:
         self._inflight = []
 
     def remove(self):
-        for h in self._handles:
+        for h in getattr(self, "_handles", []):
             h.remove()
         self._handles = []
-        if self._owns_comm and self.comm is not None:
+        try:
+            import _ops
+            _ops.GRAD_ARENA.clear()
+        except ImportError:
+            pass
+        if getattr(self, "_reserved", 0) and getattr(self, "comm", None) is not None:
+            self.comm.N.lib.ru3d_set_cu_budget(0)
+            self._reserved = 0
+        if getattr(self, "_owns_comm", False) and self.comm is not None:
             self.comm.destroy()
         self.comm = None
 

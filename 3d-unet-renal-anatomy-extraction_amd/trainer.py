@@ -279,10 +279,12 @@ class Trainer():
         """Make the ranks one job (the reference is single-process): rank 0's weights, optimizer hyper-parameters
         and train/valid split everywhere, gradient averaging on, per-rank sample streams.  Idempotent."""
         import torch.distributed as dist
-        from parallel import GradSync, broadcast_parameters
+        from parallel import make_grad_sync, broadcast_parameters
         if self._grad_sync is None:
             broadcast_parameters(self.model)
-            self._grad_sync = GradSync(self.model)
+            # all ranks end up on one transport (RCCL when every rank can load it, torch.distributed otherwise)
+            on_gpu = self.device.type == 'cuda' and dist.get_backend() != "gloo"
+            self._grad_sync = make_grad_sync(self.model, transport=os.environ.get("RU3D_COMM", "rccl" if on_gpu else "torch"))
         box = [self.train_indices, self.valid_indices, self.current_epoch]
         dist.broadcast_object_list(box, src=0)
         self.train_indices, self.valid_indices, self.current_epoch = box

@@ -243,17 +243,17 @@ def main():
     sync = None
     transport = None
     if world > 1:
-        from parallel import GradSync, broadcast_parameters
+        from parallel import make_grad_sync, broadcast_parameters
         broadcast_parameters(model)
-        transport = os.environ.get("RU3D_COMM", "torch" if one_device else "rccl")
-        gd = torch.bfloat16 if (args.grad_transport == "bf16" and transport == "rccl") else torch.float32
-        try:
-            sync = GradSync(model, transport=transport, grad_dtype=gd)
-        except Exception as e:      # e.g. no RCCL library on the box: every rank fails alike - exchange over gloo instead
-            print("bench.py rank %d: RCCL exchange unavailable (%r); falling back to torch.distributed" % (rank, e),
-                  file=sys.stderr, flush=True)
-            transport = "torch"
-            sync = GradSync(model, transport="torch")
+        want = os.environ.get("RU3D_COMM", "torch" if one_device else "rccl")
+        gd = torch.bfloat16 if (args.grad_transport == "bf16" and want == "rccl") else torch.float32
+        # every rank votes on the transport before any of them enters RCCL's collective set-up, and again on its outcome
+        # (parallel.make_grad_sync): either all ranks exchange over RCCL or all over torch.distributed
+        sync = make_grad_sync(model, transport=want, grad_dtype=gd, exchange=os.environ.get("RU3D_EXCHANGE", "allreduce"))
+        transport = sync.transport
+        if transport != want and rank == 0:
+            print("bench.py: RCCL exchange unavailable on some rank (%s); all ranks use torch.distributed" %
+                  sync.fallback_reason, file=sys.stderr, flush=True)
     if args.optimizer == "fused":
         import optim
         opt = optim.Adam(model.parameters(), lr=1e-4)      # same update rule, one launch for the whole model

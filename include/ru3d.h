@@ -358,7 +358,20 @@ int ru3d_comm_unique_id(void* id_out);
 int ru3d_comm_init(void** comm_out, const void* unique_id, int world, int rank, int device);
 /* buf: device buffer of `count` elements (RU3D_F32 or RU3D_BF16); average != 0 divides the sum by the world size. */
 int ru3d_comm_allreduce(void* comm, void* buf, int64_t count, int dtype, int average, void* stream);
+/* The same exchange as its two halves, each rank owning count_per_rank elements of the bucket (with 7
+ * point-to-point xGMI links per GPU a ring all-reduce is bound by one link; reduce-scatter + all-gather lets RCCL use
+ * its direct / mesh schedules and leaves room to run the optimizer on the owned shard between the two).  Both in place
+ * on a bucket of world * count_per_rank elements: rank r's shard is elements [r * count_per_rank, (r + 1) * ..). */
+int ru3d_comm_reduce_scatter(void* comm, void* buf, int64_t count_per_rank, int dtype, int average, void* stream);
+int ru3d_comm_all_gather(void* comm, void* buf, int64_t count_per_rank, int dtype, void* stream);
+/* 1 when librccl can be loaded in this process (no communicator is created, nothing collective happens): lets every
+ * rank vote on the transport BEFORE any rank enters the collective ru3d_comm_init. */
+int ru3d_comm_available(void);
 int ru3d_comm_destroy(void* comm);
+/* Compute units the persistent conv kernels may occupy (their grids are sized from it); 0 restores the device's count.
+ * A data-parallel rank leaves a few CUs to RCCL's reduction kernels on the side stream. */
+int ru3d_set_cu_budget(int cus);
+int ru3d_get_cu_budget(void);
 /* dst[i] = (dst_dtype)(src[i] * scale) on flat 16-byte-aligned device arrays, f32 <-> bf16: the copy-in / copy-out
  * of a bf16 gradient bucket (half the bytes over xGMI). */
 int ru3d_flat_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t count, float scale, void* stream);

@@ -96,7 +96,21 @@ def rccl_w1(out):
     torch.cuda.synchronize()
     res = {"f32_identity": bool(torch.equal(a, ref)),
            "bf16_roundtrip": bool(torch.equal(back, ref.to(torch.bfloat16).float()))}
+    # the exchange as its two halves, in place on the bucket (world of one: both are the identity)
+    c = ref.clone()
+    side.wait_stream(torch.cuda.current_stream())
+    comm.reduce_scatter(c, c.numel(), True, side)
+    comm.all_gather(c, c.numel(), side)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    res["rs_ag_identity"] = bool(torch.equal(c, ref))
+    res["available"] = int(N.lib.ru3d_comm_available())
     comm.destroy()
+    # CU budget of the persistent kernels
+    res["cu_default"] = int(N.lib.ru3d_get_cu_budget())
+    N.check(N.lib.ru3d_set_cu_budget(240), "set_cu_budget")
+    res["cu_set"] = int(N.lib.ru3d_get_cu_budget())
+    N.check(N.lib.ru3d_set_cu_budget(0), "set_cu_budget")
 
     torch.manual_seed(0)
     model = network.ResUnet3D(2, 8, 1, 2).to(dev)
@@ -122,6 +136,30 @@ def rccl_w1(out):
         res["gradsync_%s_maxerr" % ("f32" if dt == torch.float32 else "bf16")] = worst
         res["buckets"] = len(sync._buckets)
         sync.remove()
+    # the MFMA model (bf16 storage), reduce-scatter + all-gather exchange, 16 CUs left to RCCL: from the second step on
+    # the weight gradients are born inside the buckets (no copy-in), and they equal the plain run's bit for bit
+    torch.manual_seed(0)
+    model = network.ResUnet3D(2, 32, 1, 2).to(dev)
+    network.set_compute_dtype(model, torch.bfloat16)
+    model.eval()
+    L.HybirdLoss()(model(x), y).backward()
+    plain = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    sync = GradSync(model, bucket_bytes=1 << 20, transport="rccl", exchange="rs_ag", reserve_cus=16)
+    res["cu_reserved"] = int(N.lib.ru3d_get_cu_budget())
+    stats = []
+    for step in range(3):
+        model.zero_grad(set_to_none=True)
+        sync.begin_step()
+        L.HybirdLoss()(model(x), y).backward()
+        sync.finish_step()
+        torch.cuda.synchronize()
+        stats.append((sync.copied_elems, sync.inplace_elems))
+        worst = max(float((p.grad - plain[k]).abs().max()) for k, p in model.named_parameters() if p.grad is not None)
+        res["arena_step%d_maxerr" % step] = worst
+    res["arena_stats"] = stats
+    res["arena_buckets"] = len(sync._buckets)
+    sync.remove()
+    res["cu_after_remove"] = int(N.lib.ru3d_get_cu_budget())
     torch.save(res, os.path.join(out, "rccl_w1.pt"))
 
 

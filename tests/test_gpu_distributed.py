@@ -109,6 +109,18 @@ def test_rccl_wrapper_world_of_one(tmp_path):
     assert res["gradsync_f32_maxerr"] == 0.0, res
     assert res["gradsync_bf16_maxerr"] == 0.0, res
     assert res["buckets"] > 1
+    # reduce-scatter + all-gather entry points, the availability probe, the CU budget knob
+    assert res["rs_ag_identity"] and res["available"] == 1
+    assert res["cu_default"] >= 64 and res["cu_set"] == 240 and res["cu_reserved"] == res["cu_default"] - 16
+    assert res["cu_after_remove"] == res["cu_default"]
+    # GradSync(exchange="rs_ag") on the MFMA model: same gradients as the plain run; from the second step on the weight
+    # gradients are written straight into the buckets (what is still copied: biases, a few hundred elements)
+    for step in range(3):
+        assert res["arena_step%d_maxerr" % step] == 0.0, res
+    (c0, i0), (c1, i1), (c2, i2) = res["arena_stats"]
+    assert i0 == 0 and c0 > 1_000_000
+    assert c1 == c2 and c1 < 0.01 * c0 and i1 > 0.99 * c0, res["arena_stats"]
+    assert res["arena_buckets"] > 1
 
 
 def test_bench_gpus2_starts_its_own_ranks():
