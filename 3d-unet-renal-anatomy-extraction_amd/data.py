@@ -5,8 +5,10 @@
 ({'case_id', 'affine', 'image' float32 [X,Y,Z,C], 'label' int64 [X,Y,Z], 'pred'}).  NIfTI files go through nifti.py
 (nibabel when it is installed, a numpy reader / writer of the NIfTI-1 subset the reference uses otherwise); the
 affine decomposition restates transforms3d.affines.decompose / compose (a dependency of the reference that is absent
-here) for the two helpers that use it.  `orient_crop_case` (nibabel's reorientation machinery, data.py:130-175) is
-not provided: cases are expected in the orientation they were prepared in.
+here) for the two helpers that use it.  `orient_crop_case` (data.py:117-172) reorients through this module's
+restatement of nibabel's published orientation algebra (`io_orientation`, `apply_orientation`, `inv_ornt_aff`:
+nibabel is a dependency of the reference that is absent here, so those three are pinned by their defining property -
+every voxel keeps its world coordinate - not by nibabel outputs).
 """
 from pathlib import Path
 
@@ -113,6 +115,93 @@ def apply_scale(affine, scale):
 def apply_translate(affine, offset):
     t, r, z, s = _decompose(affine)
     return _compose(t + np.array(offset), r, z, s)
+
+
+# ------------------------------------------------------------------ orientation (nibabel.orientations, restated)
+def io_orientation(affine, tol=None):
+    """Orientation of the voxel axes closest to the world axes: [[output axis, +1 | -1 flip], ...] per input axis
+    (nibabel.orientations.io_orientation: polar part of the direction cosines by SVD, then a greedy
+    largest-component assignment that uses every output axis once)."""
+    affine = np.asarray(affine, dtype=np.float64)
+    q, p = affine.shape[0] - 1, affine.shape[1] - 1
+    rzs = affine[:q, :p]
+    zooms = np.sqrt(np.sum(rzs * rzs, axis=0))
+    zooms[zooms == 0] = 1
+    rs = rzs / zooms
+    u, sv, vt = np.linalg.svd(rs, full_matrices=False)
+    if tol is None:
+        tol = sv.max() * max(rs.shape) * np.finfo(sv.dtype).eps
+    keep = sv > tol
+    r = np.dot(u[:, keep], vt[keep])
+    ornt = np.ones((p, 2), dtype=np.float64) * np.nan
+    for in_ax in range(p):
+        col = r[:, in_ax]
+        if not np.allclose(col, 0):
+            out_ax = int(np.argmax(np.abs(col)))
+            ornt[in_ax, 0] = out_ax
+            ornt[in_ax, 1] = -1 if col[out_ax] < 0 else 1
+            r[out_ax, :] = 0          # this output axis is taken
+    return ornt
+
+
+def apply_orientation(arr, ornt):
+    """Flip, then permute, the leading axes of `arr` as `ornt` says (nibabel.orientations.apply_orientation)."""
+    t = np.asarray(arr)
+    ornt = np.asarray(ornt)
+    n = ornt.shape[0]
+    if t.ndim < n:
+        raise ValueError("data array has fewer dimensions than the orientation")
+    if np.any(np.isnan(ornt[:, 0])):
+        raise ValueError("cannot reorient along a dropped axis")
+    for ax, flip in enumerate(ornt[:, 1]):
+        if flip == -1:
+            t = np.flip(t, axis=ax)
+    full = np.arange(t.ndim)
+    full[:n] = np.argsort(ornt[:, 0])
+    return t.transpose(full)
+
+
+def inv_ornt_aff(ornt, shape):
+    """Affine from the reoriented array's voxel indices back to the original's (nibabel.orientations.inv_ornt_aff)."""
+    ornt = np.asarray(ornt)
+    p = ornt.shape[0]
+    shape = np.array(shape)[:p]
+    undo_reorder = np.eye(p + 1)[list(ornt[:, 0].astype(int)) + [p], :]
+    undo_flip = np.diag(list(ornt[:, 1]) + [1.0])
+    center = -(shape - 1) / 2.0
+    undo_flip[:p, p] = ornt[:, 1] * center - center
+    return np.dot(undo_flip, undo_reorder)
+
+
+def reorient(array, affine, ornt):
+    """(array, affine) after `ornt` - what nibabel's `Nifti1Pair(array, affine).as_reoriented(ornt)` holds."""
+    return apply_orientation(array, ornt), np.dot(np.asarray(affine, dtype=np.float64), inv_ornt_aff(ornt, np.asarray(array).shape))
+
+
+def orient_crop_case(case, air=-200):
+    """data.py:117-172: reorient the case to the closest-to-canonical axes, then crop it to the bounding box of the voxels
+    above `air` (in any channel); 'bbox' records the box, the affine moves with the crop."""
+    case = case.copy()
+    ornt = io_orientation(case['affine'])
+    image, new_affine = reorient(case['image'], case['affine'], ornt)
+    image = image.astype(np.float32)
+    if 'label' in case:
+        label = apply_orientation(case['label'], ornt).astype(np.int64)
+    if image.ndim == 3:
+        image = image[..., None]
+    lo, hi = [], []
+    for channel in split_dim(image):
+        pos = np.array(np.where(channel > air))
+        lo.append(pos.min(axis=1))
+        hi.append(pos.max(axis=1))
+    bbox = np.array([np.array(lo).min(axis=0), np.array(hi).max(axis=0)]).T          # (3, 2): as in the reference, the
+    bbox_c = np.concatenate([bbox, [[0, image.shape[-1]]]])                          # upper bound is the last index itself
+    case['image'] = crop_pad_to_bbox(image, bbox_c)
+    case['bbox'] = bbox
+    if 'label' in case:
+        case['label'] = crop_pad_to_bbox(label, bbox)
+    case['affine'] = apply_translate(new_affine, bbox[:, 0] * np.array(get_spacing(new_affine)))
+    return case
 
 
 # ------------------------------------------------------------------ preparation (data.py:222-283, 464-492)

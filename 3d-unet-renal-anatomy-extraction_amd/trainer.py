@@ -523,6 +523,48 @@ def cascade_predict_case(case, coarse_model, coarse_target_spacing, coarse_norma
     return case
 
 
+def cascade_predict(image_file, coarse_model, coarse_target_spacing, coarse_normalize_stats, coarse_patch_size,
+                    detail_model, detail_target_spacing, detail_normalize_stats, detail_patch_size, air=-200, num_classes=3,
+                    step_per_patch=4, region_threshold=10000, crop_padding=20, label_file=None, verbose=True):
+    """trainer.py:248-302: load a NIfTI image, reorient + crop it to its non-air box, run the cascade on the crop, and
+    put the mask back into a volume of the original file's grid.  As in the reference the final step applies the
+    forward orientation once more (`apply_orientation(orig_pred, orient)`), which undoes the first one for the
+    orientations that are their own inverse - every pure flip, and the usual axis swaps."""
+    from data import apply_orientation, io_orientation, load_case, orient_crop_case
+    orig_case = load_case(image_file, label_file)
+    case = orient_crop_case(orig_case, air)
+    case = cascade_predict_case(case, coarse_model, coarse_target_spacing, coarse_normalize_stats, coarse_patch_size,
+                                detail_model, detail_target_spacing, detail_normalize_stats, detail_patch_size,
+                                num_classes, step_per_patch, region_threshold, crop_padding, verbose)
+    ornt = io_orientation(orig_case['affine'])
+    order = ornt[:, 0].astype(int)
+    orig_shape = np.take(np.array(orig_case['image'].shape[:3]), order)
+    bbox = case['bbox']
+    orig_pred = np.zeros(orig_shape, dtype=np.uint8)
+    target = tuple(slice(max(bbox[d][0], 0), min(bbox[d][1], orig_shape[d])) for d in range(3))
+    orig_pred[target] = case['pred']
+    orig_case['pred'] = apply_orientation(orig_pred, ornt)
+    if orig_case['image'].ndim == 3:
+        orig_case['image'] = np.expand_dims(orig_case['image'], -1)
+    return orig_case
+
+
+def batch_cascade_predict(image_dir, save_dir, coarse_model, coarse_target_spacing, coarse_normalize_stats,
+                          coarse_patch_size, detail_model, detail_target_spacing, detail_normalize_stats,
+                          detail_patch_size, air=-200, num_classes=3, step_per_patch=4, region_threshold=10000,
+                          crop_padding=20, data_range=None):
+    """trainer.py:305-345: every file of `image_dir` through cascade_predict, masks written with save_pred."""
+    from pathlib import Path
+    from data import save_pred
+    image_files = [path for path in sorted(Path(image_dir).iterdir()) if path.is_file()]
+    for i in (data_range if data_range is not None else range(len(image_files))):
+        case = cascade_predict(image_files[i], coarse_model, coarse_target_spacing, coarse_normalize_stats,
+                               coarse_patch_size, detail_model, detail_target_spacing, detail_normalize_stats,
+                               detail_patch_size, air, num_classes, step_per_patch, region_threshold, crop_padding,
+                               None, False)
+        save_pred(case, save_dir)
+
+
 def evaluate_case(case):
     """trainer.py:348-356: Dice (loss.dice, alpha = beta = 0.5) of every foreground class of label vs pred."""
     out = []

@@ -221,3 +221,89 @@ def test_predict_case_device_pipeline_vs_host_composition():
         else:
             assert got.dtype == np.uint8
             assert (got != want).mean() <= 2e-3          # interpolation ulps can move a voxel that sits on a tie
+
+
+# --------------------------------------------------------------------------- cascade (fixture G9)
+def _g9_models(golden_dir):
+    z = np.load(os.path.join(golden_dir, "g9_cascade.npz"))
+    coarse = network.ResUnet3D(num_pool=2, num_features=4, in_channels=1, out_channels=1)
+    detail = network.ResUnet3D(num_pool=2, num_features=4, in_channels=1, out_channels=3)
+    coarse.load_state_dict({k[len("coarse/w/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("coarse/w/")}, strict=True)
+    detail.load_state_dict({k[len("detail/w/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("detail/w/")}, strict=True)
+    stats = dict(zip(("mean", "std", "pct_00_5", "pct_99_5"), (float(v) for v in z["stats"])))
+    kw = dict(coarse_target_spacing=tuple(z["params"][0]), coarse_normalize_stats=stats,
+              coarse_patch_size=tuple(int(v) for v in z["patches"][0]), detail_target_spacing=tuple(z["params"][1]),
+              detail_normalize_stats=stats, detail_patch_size=tuple(int(v) for v in z["patches"][1]),
+              step_per_patch=int(z["scalars"][0]), region_threshold=int(z["scalars"][1]), crop_padding=int(z["scalars"][2]))
+    return z, coarse.to(DEV).eval(), detail.to(DEV).eval(), kw
+
+
+def test_cascade_predict_case_vs_reference_fixture(golden_dir):
+    """trainer.cascade_predict_case (reference trainer.py:164-245) on the HIP path against G9 - the reference's own
+    coarse mask, regions and per-region probability maps, merged by the reference's arithmetic: the coarse mask agrees
+    except on voxels within 1e-4 of the 0.5 threshold (none here), every region's probabilities within 2e-4 (the
+    device resampling differs from scipy's by interpolation ulps, test_predict_case_device_pipeline_vs_host_composition),
+    the final mask identical except where the merged top-2 margin is below 1e-3."""
+    import data
+    z, coarse, detail, kw = _g9_models(golden_dir)
+    case = {"case_id": "g9", "image": z["image"], "affine": z["affine"]}
+    c1 = T.predict_case(dict(case), coarse, kw["coarse_target_spacing"], kw["coarse_normalize_stats"], 1,
+                        kw["coarse_patch_size"], kw["step_per_patch"], verbose=False)
+    assert c1["pred"].dtype == np.uint8 and (c1["pred"] != z["coarse_pred"]).mean() <= 1e-3
+    regions = data.regions_crop_case({**case, "pred": z["coarse_pred"]}, kw["region_threshold"], kw["crop_padding"], "pred")
+    assert [r["bbox"].tolist() for r in regions] == z["regions"].tolist()
+    for i, region in enumerate(regions):
+        out = T.predict_case(region, detail, kw["detail_target_spacing"], kw["detail_normalize_stats"], 3,
+                             kw["detail_patch_size"], kw["step_per_patch"], verbose=False, one_hot=True)["pred"]
+        want = z["region%d/prob" % i]
+        ok = np.isfinite(want)
+        assert out.shape == want.shape and np.array_equal(ok, np.isfinite(out))
+        assert np.abs(out[ok] - want[ok]).max() <= 2e-4
+    res = T.cascade_predict_case(dict(case), coarse, kw["coarse_target_spacing"], kw["coarse_normalize_stats"],
+                                 kw["coarse_patch_size"], detail, kw["detail_target_spacing"], kw["detail_normalize_stats"],
+                                 kw["detail_patch_size"], 3, kw["step_per_patch"], kw["region_threshold"], kw["crop_padding"],
+                                 verbose=False)
+    assert res["pred"].dtype == np.uint8 and res["pred"].shape == z["pred"].shape
+    assert sorted(np.unique(res["pred"]).tolist()) == sorted(np.unique(z["pred"]).tolist())
+    assert (res["pred"] != z["pred"]).mean() <= 2e-3
+
+
+def test_cascade_predict_from_files_restores_the_original_grid(golden_dir, tmp_path):
+    """trainer.cascade_predict / batch_cascade_predict (reference trainer.py:248-345): the G9 volume stored with two
+    flipped axes and an air margin comes back as a mask on the FILE's grid; inside the non-air box it is the cascade's
+    mask of the reoriented crop, outside it is background."""
+    import data
+    import nifti
+    z, coarse, detail, kw = _g9_models(golden_dir)
+    vol = z["image"][..., 0]
+    padded = np.full(tuple(s + 6 for s in vol.shape), -1000.0, dtype=np.float32)
+    padded[2:-4, 3:-3, 1:-5] = vol
+    flipped = padded[::-1, :, ::-1].copy()                       # stored right-to-left and top-to-bottom
+    aff = np.diag([-1.6, 1.6, -3.0, 1.0])
+    aff[:3, 3] = [40.0, 14.0, 60.0]
+    idir = tmp_path / "images"
+    idir.mkdir()
+    nifti.save(flipped, aff, idir / "case_7.nii.gz")
+    out = T.cascade_predict(idir / "case_7.nii.gz", coarse, kw["coarse_target_spacing"], kw["coarse_normalize_stats"],
+                            kw["coarse_patch_size"], detail, kw["detail_target_spacing"], kw["detail_normalize_stats"],
+                            kw["detail_patch_size"], air=-200, step_per_patch=kw["step_per_patch"],
+                            region_threshold=kw["region_threshold"], crop_padding=kw["crop_padding"], verbose=False)
+    assert out["pred"].shape == flipped.shape and out["pred"].dtype == np.uint8 and out["image"].shape == flipped.shape + (1,)
+    # the same mask, computed by hand: reorient, crop, cascade, paste, orient back (a double flip is its own inverse)
+    case = data.orient_crop_case({"case_id": "case_7", "image": flipped[..., None], "affine": aff}, -200)
+    ref = T.cascade_predict_case(dict(case), coarse, kw["coarse_target_spacing"], kw["coarse_normalize_stats"],
+                                 kw["coarse_patch_size"], detail, kw["detail_target_spacing"], kw["detail_normalize_stats"],
+                                 kw["detail_patch_size"], 3, kw["step_per_patch"], kw["region_threshold"], kw["crop_padding"],
+                                 verbose=False)["pred"]
+    canon = np.zeros(padded.shape, dtype=np.uint8)
+    bb = case["bbox"]
+    canon[tuple(slice(b[0], b[1]) for b in bb)] = ref
+    assert np.array_equal(out["pred"], canon[::-1, :, ::-1])
+    assert out["pred"].max() >= 1 and not out["pred"][:, :, :4].any()     # the air margin stays background
+    sdir = tmp_path / "preds"
+    T.batch_cascade_predict(idir, sdir, coarse, kw["coarse_target_spacing"], kw["coarse_normalize_stats"],
+                            kw["coarse_patch_size"], detail, kw["detail_target_spacing"], kw["detail_normalize_stats"],
+                            kw["detail_patch_size"], air=-200, step_per_patch=kw["step_per_patch"],
+                            region_threshold=kw["region_threshold"], crop_padding=kw["crop_padding"])
+    saved, saved_aff, _ = nifti.load(sdir / "case_7.pred.nii.gz")
+    assert np.array_equal(saved.astype(np.uint8), out["pred"]) and np.allclose(saved_aff, aff)

@@ -116,3 +116,99 @@ def test_case_dataset_and_preparation(tmp_path):
     data.save_pred(case, tmp_path / "pred")
     import trainer
     assert trainer.evaluate(tmp_path / "case_01.label.nii.gz", tmp_path / "pred" / "case_01.pred.nii.gz") == [1.0, 1.0]
+
+
+# --------------------------------------------------------------------------- cascade / evaluation glue (fixture G9)
+def _g9(golden_dir):
+    return np.load(os.path.join(golden_dir, "g9_cascade.npz"))
+
+
+def test_evaluate_case_and_batch_evaluate_vs_reference_fixture(golden_dir, tmp_path, capsys):
+    """trainer.evaluate_case (reference trainer.py:348-356) on the G9 label / prediction pair = the reference's own
+    numbers; evaluate / batch_evaluate (:359-400) read the same pair back from .nii.gz files."""
+    import trainer
+    z = _g9(golden_dir)
+    got = trainer.evaluate_case({"label": z["eval_label"], "pred": z["pred"]})
+    assert len(got) == int(z["eval_label"].max()) == 3
+    assert np.allclose(got, z["eval_dice"], rtol=0, atol=1e-6)
+    ldir, pdir = tmp_path / "labels", tmp_path / "preds"
+    ldir.mkdir()
+    pdir.mkdir()
+    aff = np.diag([1.6, 1.6, 3.0, 1.0])
+    for i in range(2):      # case 1: a perfect prediction
+        nifti.save(z["eval_label"], aff, ldir / ("case_%d.nii.gz" % i))
+        nifti.save(z["pred"] if i == 0 else z["eval_label"], aff, pdir / ("case_%d.nii.gz" % i))
+    assert np.allclose(trainer.evaluate(ldir / "case_0.nii.gz", pdir / "case_0.nii.gz"), z["eval_dice"], atol=1e-6)
+    res = trainer.batch_evaluate(ldir, pdir)
+    assert len(res) == 2 and np.allclose(res[0], z["eval_dice"], atol=1e-6) and np.allclose(res[1], 1.0, atol=1e-6)
+    assert "label_1:" in capsys.readouterr().out
+    assert len(trainer.batch_evaluate(ldir, pdir, data_range=[1])) == 1
+
+
+def test_regions_crop_case_vs_reference_fixture(golden_dir):
+    """data.regions_crop_case on the reference's coarse mask gives the reference's regions (bounding boxes incl. the
+    millimetre padding) and crops that carry the padded box's shape."""
+    z = _g9(golden_dir)
+    case = {"case_id": "g9", "image": z["image"], "affine": z["affine"], "pred": z["coarse_pred"]}
+    thr, pad = int(z["scalars"][1]), int(z["scalars"][2])
+    regions = data.regions_crop_case(case, thr, pad, "pred")
+    assert len(regions) == len(z["regions"]) == 2
+    for r, bbox in zip(regions, z["regions"]):
+        assert np.array_equal(r["bbox"], bbox)
+        assert r["image"].shape[:3] == tuple(int(b[1] - b[0]) for b in bbox)
+        # the affine moves with the box: its origin is the box's first voxel in world coordinates
+        assert np.allclose(r["affine"][:3, 3], z["affine"][:3, 3] + bbox[:, 0] * np.array(data.get_spacing(z["affine"])))
+
+
+def test_orientation_algebra_keeps_world_coordinates():
+    """data.io_orientation / apply_orientation / inv_ornt_aff (nibabel's published algorithm, restated - nibabel is not
+    installed here, so the pin is the defining property): after reorientation the axes are the closest to canonical
+    (diagonally dominant, positive) and every voxel keeps its value and its world coordinate."""
+    rng = np.random.RandomState(0)
+    for trial in range(40):
+        perm, flips = rng.permutation(3), rng.choice([-1, 1], 3)
+        r = np.zeros((3, 3))
+        for i in range(3):
+            r[perm[i], i] = flips[i]
+        a, b, c = rng.randn(3) * 0.12        # a small rotation on top of the signed permutation
+        rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+        rz = np.array([[np.cos(c), -np.sin(c), 0], [np.sin(c), np.cos(c), 0], [0, 0, 1]])
+        aff = np.eye(4)
+        aff[:3, :3] = rx @ ry @ rz @ r @ np.diag(rng.rand(3) * 2 + 0.5)
+        aff[:3, 3] = rng.randn(3) * 30
+        shape = tuple(rng.randint(3, 8, 3))
+        arr = rng.rand(*shape)
+        ornt = data.io_orientation(aff)
+        assert sorted(ornt[:, 0]) == [0, 1, 2] and set(np.abs(ornt[:, 1])) == {1}
+        arr2, aff2 = data.reorient(arr, aff, ornt)
+        assert all(np.argmax(np.abs(aff2[:3, i])) == i and aff2[i, i] > 0 for i in range(3))
+        idx = np.array([rng.randint(0, s) for s in shape])
+        j = np.linalg.solve(data.inv_ornt_aff(ornt, shape), np.append(idx, 1))[:3]
+        jj = np.round(j).astype(int)
+        assert np.allclose(j, jj) and arr2[tuple(jj)] == arr[tuple(idx)]
+        assert np.allclose(aff2 @ np.append(jj, 1), aff @ np.append(idx, 1))
+    # the identity orientation changes nothing
+    ornt = data.io_orientation(np.diag([2.0, 1.0, 3.0, 1.0]))
+    assert np.array_equal(ornt, [[0, 1], [1, 1], [2, 1]])
+
+
+def test_orient_crop_case_boxes_the_non_air_voxels():
+    """data.orient_crop_case (reference data.py:117-172) on a flipped / permuted acquisition: canonical axes, the box of
+    the voxels above `air` (upper bound = last index, as the reference computes it), label cropped alike, affine moved."""
+    rng = np.random.RandomState(3)
+    vol = np.full((12, 10, 9), -1000.0, dtype=np.float32)
+    vol[3:8, 2:7, 4:8] = rng.rand(5, 5, 4).astype(np.float32) * 100
+    label = (vol > 0).astype(np.int64)
+    aff = np.array([[0, -1.5, 0, 10.0], [2.0, 0, 0, -4.0], [0, 0, -3.0, 7.0], [0, 0, 0, 1.0]])   # axes swapped, two flipped
+    case = data.orient_crop_case({"case_id": "c", "image": vol, "label": label, "affine": aff}, air=-200)
+    ornt = data.io_orientation(aff)
+    vol_r, aff_r = data.reorient(vol, aff, ornt)
+    pos = np.array(np.where(vol_r > -200))
+    bbox = np.array([pos.min(axis=1), pos.max(axis=1)]).T
+    assert np.array_equal(case["bbox"], bbox)
+    assert case["image"].shape == tuple(bbox[:, 1] - bbox[:, 0]) + (1,)
+    assert np.array_equal(case["image"][..., 0], vol_r[tuple(slice(b[0], b[1]) for b in bbox)])
+    assert np.array_equal(case["label"], data.apply_orientation(label, ornt)[tuple(slice(b[0], b[1]) for b in bbox)])
+    assert np.allclose(case["affine"][:3, 3], (aff_r @ np.append(bbox[:, 0], 1))[:3])
+    assert np.allclose(data.get_spacing(case["affine"]), data.get_spacing(aff_r))
