@@ -225,3 +225,112 @@ def test_config5_training_step_deterministic_and_checkpoint_bit_equal():
         for k in keys:
             assert torch.equal(a[2][k], other[2][k]), k
     assert c[3] < 0.62 * a[3], (a[3], c[3])
+
+
+# --------------------------------------------------------------------------- BASELINE config 4 (F = 30 padded, fp16, 160 x 160 x 80)
+D4 = (160, 160, 80)
+
+
+def test_config4_tap_count_identities_non_cubic_fp16():
+    """The non-cubic 2 x 160 x 160 x 80 grid of config 4 in fp16 storage, 32 (= 30 padded) channels: every tile edge of
+    the sliding / stride-2 / transposed kernels on extents that are not powers of two (160 = 5 x 32, 80, 40 = 2.5 x 16)."""
+    n, c = 2, 32
+    H = torch.float16
+    d, h, w = D4
+    x = N.new_act(n, c, d, h, w, H, DEV)
+    x.fill_(1.0)
+    wt = torch.full((c, c, 3, 3, 3), 1.0 / c, device=DEV)
+    y = ops.conv_fwd(x, ops.pack_weight(wt, N.ROLE_CONV_FWD, H, 1), None, c, 3, 1)
+    assert torch.equal(y.float(), _valid_counts(d, h, w).to(DEV)[None, None].expand(n, c, d, h, w))
+    del y
+    gw = ops.conv_wgrad(x, x, 3, 1)
+    ax = [torch.tensor([s - 1.0, s, s - 1.0]) for s in D4]
+    expect = n * ax[0][:, None, None] * ax[1][None, :, None] * ax[2][None, None, :]
+    assert torch.equal(gw.cpu(), expect[None, None].expand(c, c, 3, 3, 3))
+    del gw
+    # stride-2 pooling conv 32 -> 64 (LDS-DMA gather form: 40 = 2.5 tiles of 16 along W) ...
+    w2 = torch.full((2 * c, c, 3, 3, 3), 1.0 / c, device=DEV)
+    y2 = ops.conv_fwd(x, ops.pack_weight(w2, N.ROLE_CONV_FWD, H, 2), None, 2 * c, 3, 2)
+
+    def axis2(m):
+        v = torch.full((m,), 3.0)
+        v[0] = 2.0
+        return v
+    c2 = axis2(d // 2)[:, None, None] * axis2(h // 2)[None, :, None] * axis2(w // 2)[None, None, :]
+    assert torch.equal(y2.float(), c2.to(DEV)[None, None].expand(n, 2 * c, d // 2, h // 2, w // 2))
+    # ... and its transposed-form input gradient: dx[i] = number of outputs whose window holds i
+    gy = N.new_act(n, 2 * c, d // 2, h // 2, w // 2, H, DEV)
+    gy.fill_(1.0)
+    wd = torch.full((2 * c, c, 3, 3, 3), 1.0 / (2 * c), device=DEV)
+    gx = ops.conv_dgrad(gy, ops.pack_weight(wd, N.ROLE_CONV_DGRAD, H, 2), (n, c, d, h, w), 3, 2)
+
+    def axisT(m):          # voxel i is read by outputs o with 2o-1 <= i <= 2o+1: two for odd i < m-1, one for even i and i = m-1
+        v = torch.ones(m)
+        v[1::2] = 2.0
+        v[m - 1] = 1.0
+        return v
+    ct = axisT(d)[:, None, None] * axisT(h)[None, :, None] * axisT(w)[None, None, :]
+    assert torch.equal(gx.float(), ct.to(DEV)[None, None].expand(n, c, d, h, w))
+    # ConvTranspose 64 -> 32 from the half-resolution grid: the far planes are zero, the rest counts its taps
+    xt = N.new_act(n, 2 * c, d // 2, h // 2, w // 2, H, DEV)
+    xt.fill_(1.0)
+    wtt = torch.full((2 * c, c, 3, 3, 3), 1.0 / (2 * c), device=DEV)
+    yt = ops.convt_fwd(xt, ops.pack_weight(wtt, N.ROLE_CONVT_FWD, H), None, c)
+
+    def axisU(m):          # output o of the (2m-1)-long transposed conv: one tap for even o, two for odd o; o = 2m-1 is the pad
+        v = torch.ones(m)
+        v[1::2] = 2.0
+        v[m - 1] = 0.0
+        return v
+    cu = axisU(d)[:, None, None] * axisU(h)[None, :, None] * axisU(w)[None, None, :]
+    assert torch.equal(yt.float(), cu.to(DEV)[None, None].expand(n, c, d, h, w))
+
+
+def test_config4_step_deterministic_and_forward_vs_oracle_fp16():
+    """ResUnet3D(4, 30, 1, 3) (85 M parameters, channels padded 30 -> 32) in fp16 storage on config 4's 160 x 160 x 80
+    patches: two training steps at bs = 2 give the same bits; a bs = 1 forward stays within the fp16 storage model's
+    distance of the fp32 CPU oracle (err_HIP <= 1.5 err_model + 2e-3, argmax flips only inside the margin band, per-class
+    Dice of the masks > 0.99)."""
+    H = torch.float16
+    torch.manual_seed(0)
+    model = network.ResUnet3D(4, 30, 1, 3).to(DEV).eval()
+    network.set_compute_dtype(model, H)
+    assert model.net._pad
+    x = O.synth_image((2, 1) + D4, 44).to(DEV)
+    y = torch.randint(0, 3, (2,) + D4, generator=torch.Generator().manual_seed(4)).to(DEV)
+    crit = L.HybirdLoss(weight_v=[1, 148, 191], alpha=0.9, beta=0.1)      # nb_train_iib.py:19
+    runs = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        logits = model(x)
+        loss = crit(logits, y) * 1024.0          # a loss scale that keeps the fp16 gradients in range
+        loss.backward()
+        runs.append((logits.detach().clone(), float(loss.detach()),
+                     {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+    for k in runs[0][2]:
+        assert torch.equal(runs[0][2][k], runs[1][2][k]), k
+        assert torch.isfinite(runs[0][2][k]).all(), k
+    assert len(runs[0][2]) == 66
+    del runs
+    model.zero_grad(set_to_none=True)
+    w = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    x1 = O.synth_image((1, 1) + D4, 45)
+    with torch.no_grad():
+        got = model(x1.to(DEV)).cpu()
+        torch.set_num_threads(min(16, torch.get_num_threads()))
+        ref = O.unet_forward(x1, w, 4)
+        O.set_storage(H)
+        try:
+            sim = O.unet_forward(x1, w, 4)
+        finally:
+            O.set_storage(None)
+    e_hip, e_sim = (got - ref).abs().max().item(), (sim - ref).abs().max().item()
+    assert e_hip <= 1.5 * e_sim + 2e-3, (e_hip, e_sim)
+    top2 = ref.topk(2, dim=1).values
+    flips = got.argmax(1) != ref.argmax(1)
+    assert not (flips & ((top2[:, 0] - top2[:, 1]) > 4 * e_sim + 2e-3)).any()
+    for c in range(3):
+        a, b = (got.argmax(1) == c).float(), (ref.argmax(1) == c).long()
+        if b.sum() > 0:
+            assert O.tversky(a, b).item() > 0.99
