@@ -359,7 +359,15 @@ class ResBlock(nn.Module):
             return (keep.reshape(-1) / (1.0 - p)).contiguous()
         if p == 0.0:
             return None
-        return ops.dropout_scale(n, c, p, x.device)
+        pooled = ops.take_dropout(n, c, p)      # Unet.forward drew the whole pass's factors in one launch
+        return pooled if pooled is not None else ops.dropout_scale(n, c, p, x.device)
+
+    def _drop_spec(self, n):
+        """(n, c, p) of the draw this block will make in training mode, or None (same conditions as _drop_scale)."""
+        if (not self._native or self.dropout is None or not self.training or self._forced_keep is not None
+                or float(self.dropout.p) == 0.0):
+            return None
+        return (n, ops.cpad(self.out_channels) if self._pad else self.out_channels, float(self.dropout.p))
 
     def forward(self, x, in_link=None, out_link=None):
         """in_link / out_link: ops.SkipLink objects Unet passes to the pooling block / the last encoder block of a
@@ -579,6 +587,21 @@ class Unet(nn.Module):
         x = self._stem(x)
         skips, links = [], []
         linked = self._linked and x.is_cuda
+        if linked and self.training:
+            # every Dropout3d factor of the pass from one launch (ops.prefill_dropout), in the blocks' execution order
+            order = []
+            for i in range(self.num_pool):
+                order += [self.encode_blocks[i], self.pool_blocks[i]]
+            order += [self.encode_blocks[-1]]
+            for i in reversed(range(self.num_pool)):
+                order += [self.decode_blocks[i]]
+            specs = []
+            for m in order:
+                for blk in (m.res_blocks if isinstance(m, ResBlockStack) else [m]):
+                    sp = blk._drop_spec(x.shape[0]) if isinstance(blk, ResBlock) else None
+                    if sp is not None:
+                        specs.append(sp)
+            ops.prefill_dropout(specs, x.device)
         for i in range(self.num_pool):
             link = None
             if linked:
@@ -594,6 +617,7 @@ class Unet(nn.Module):
         for i in reversed(range(self.num_pool)):
             x = self.up_blocks[i](x, skips[i], links[i]) if linked else self.up_blocks[i](x, skips[i])
             x = self.decode_blocks[i](x)
+        ops._DROP_POOL.clear()
         return self._head(x)
 
 
