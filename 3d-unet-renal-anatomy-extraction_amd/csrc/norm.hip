@@ -69,7 +69,10 @@ template <typename T, int VEC, int MODE>
 __global__ __launch_bounds__(256) void reduce2_kernel(const T* __restrict__ a, int lda, const T* __restrict__ b,
                                                       int ldb, const T* __restrict__ c3, int ldc,
                                                       const float* __restrict__ mean, const float* __restrict__ scale,
-                                                      float slope, double* __restrict__ part, ChanLoop cl, int C) {
+                                                      float slope, double* __restrict__ part, ChanLoop cl, int C,
+                                                      T* __restrict__ gp_out = nullptr, int ldgp = 0) {
+    // MODE 4 = MODE 1 that also stores g' = gout * lrelu'(out) (the pre-activation gradient): the apply pass then reads
+    // (g', y) instead of (gout, out, y) - one tensor pass fewer per residual block backward
     __shared__ double sh[2][256][VEC > 4 ? 4 : VEC];  // reduced in two halves when VEC == 8
     const int tid = threadIdx.x;
     const int cgl = tid % cl.Gb, vl = tid / cl.Gb;
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(256) void reduce2_kernel(const T* __restrict__ a, i
     for (int i = 0; i < VEC; i++) s1[i] = s2[i] = 0.f;
     if (active) {
         float mu[VEC], sc[VEC];
-        if (MODE == 1) {
+        if (MODE == 1 || MODE == 4) {
 #pragma unroll
             for (int i = 0; i < VEC; i++) {
                 mu[i] = mean[n * C + cg * VEC + i];
@@ -101,17 +104,20 @@ __global__ __launch_bounds__(256) void reduce2_kernel(const T* __restrict__ a, i
                     s1[i] += av[i];
                     s2[i] = fmaf(av[i], av[i], s2[i]);
                 }
-            } else if (MODE == 1) {
-                float ov[VEC], yv[VEC];
+            } else if (MODE == 1 || MODE == 4) {
+                float ov[VEC], yv[VEC], pv[VEC];
                 load_vec<T, VEC>(b + row * ldb + cg * VEC, ov);
                 load_vec<T, VEC>(c3 + row * ldc + cg * VEC, yv);
 #pragma unroll
                 for (int i = 0; i < VEC; i++) {
-                    const float gp = ov[i] > 0.f ? av[i] : av[i] * slope;
+                    float gp = ov[i] > 0.f ? av[i] : av[i] * slope;
+                    if (MODE == 4) gp = to_f32<T>(from_f32<T>(gp));      // the sums see the value the apply pass will read
+                    pv[i] = gp;
                     const float xh = (yv[i] - mu[i]) * sc[i];
                     s1[i] += gp;
                     s2[i] = fmaf(gp, xh, s2[i]);
                 }
+                if (MODE == 4) store_vec<T, VEC>(gp_out + row * ldgp + cg * VEC, pv);
             } else if (MODE == 3) {
                 float ov[VEC];
                 load_vec<T, VEC>(b + row * ldb + cg * VEC, ov);
@@ -297,7 +303,8 @@ __global__ __launch_bounds__(256) void in_lrelu_fwd_kernel(const T* __restrict__
 }
 
 // dy = scale * (gpre - m1 - xhat * m2), gpre = gout * lrelu'(out); optional gpre output; far planes zeroed
-template <typename T, int VEC, bool HAS_GPRE>
+// FROM_GPRE: `gpre` is an INPUT (written by reduce2 MODE 4): dy from (gpre, y) alone
+template <typename T, int VEC, bool HAS_GPRE, bool FROM_GPRE = false>
 __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(const T* __restrict__ gout, int ldg,
                                                            const T* __restrict__ out, int ldo,
                                                            const T* __restrict__ y, int ldy,
@@ -329,8 +336,12 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(const T* __restrict__
     for (int v = v0 + vl; v < v1; v += cl.vpb) {
         const int64_t row = (int64_t)n * cl.V + v;
         float gv[VEC], ov[VEC], yv[VEC], dv[VEC], pv[VEC];
-        load_vec<T, VEC>(gout + row * ldg + cg * VEC, gv);
-        load_vec<T, VEC>(out + row * ldo + cg * VEC, ov);
+        if (FROM_GPRE) {
+            load_vec<T, VEC>(gpre + row * ldgp + cg * VEC, gv);
+        } else {
+            load_vec<T, VEC>(gout + row * ldg + cg * VEC, gv);
+            load_vec<T, VEC>(out + row * ldo + cg * VEC, ov);
+        }
         if (HAS_GPRE) load_vec<T, VEC>(y + row * ldy + cg * VEC, yv);   // no residual: xhat comes from `out`
         bool far = false;
         if (zero_far) {
@@ -343,13 +354,13 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(const T* __restrict__
         }
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
-            const float gp = ov[i] > 0.f ? gv[i] : gv[i] * slope;
+            const float gp = FROM_GPRE ? gv[i] : (ov[i] > 0.f ? gv[i] : gv[i] * slope);
             const float xh = HAS_GPRE ? (yv[i] - mu[i]) * sc[i] : (ov[i] > 0.f ? ov[i] : ov[i] * inv_slope);
             pv[i] = gp;
             dv[i] = far ? 0.f : sc[i] * (gp - m1[i] - xh * m2[i]);
         }
         store_vec<T, VEC>(dy + row * lddy + cg * VEC, dv);
-        if (HAS_GPRE) store_vec<T, VEC>(gpre + row * ldgp + cg * VEC, pv);
+        if (HAS_GPRE && !FROM_GPRE) store_vec<T, VEC>(gpre + row * ldgp + cg * VEC, pv);
     }
 }
 
@@ -525,9 +536,9 @@ static int in_bwd_impl(const ru3d_tensor* gout, const ru3d_tensor* out, const ru
     float* m12 = (float*)((char*)ws + (size_t)y->n * cl.chunks * y->c * 2 * sizeof(double));
 #define CALL(TT, VV)                                                                                                  \
     if (gpre)                                                                                                         \
-        hipLaunchKernelGGL((reduce2_kernel<TT, VV, 1>), grid, dim3(256), 0, st, (const TT*)gout->ptr, gout->ld,       \
+        hipLaunchKernelGGL((reduce2_kernel<TT, VV, 4>), grid, dim3(256), 0, st, (const TT*)gout->ptr, gout->ld,       \
                            (const TT*)out->ptr, out->ld, (const TT*)y->ptr, y->ld, mean, scale, slope, part, cl,      \
-                           y->c);                                                                                     \
+                           y->c, (TT*)gpre->ptr, gpre->ld);                                                           \
     else                                                                                                              \
         hipLaunchKernelGGL((reduce2_kernel<TT, VV, 3>), grid, dim3(256), 0, st, (const TT*)gout->ptr, gout->ld,       \
                            (const TT*)out->ptr, out->ld, (const TT*)0, 0, mean, scale, slope, part, cl, y->c)
@@ -543,7 +554,7 @@ static int in_bwd_impl(const ru3d_tensor* gout, const ru3d_tensor* out, const ru
     dim3 grida(ca.chunks, y->n, (ca.G + ca.Gb - 1) / ca.Gb);
 #define CALL(TT, VV)                                                                                                  \
     if (gpre)                                                                                                         \
-        hipLaunchKernelGGL((in_lrelu_bwd_kernel<TT, VV, true>), grida, dim3(256), 0, st, (const TT*)gout->ptr,        \
+        hipLaunchKernelGGL((in_lrelu_bwd_kernel<TT, VV, true, true>), grida, dim3(256), 0, st, (const TT*)gout->ptr,  \
                            gout->ld, (const TT*)out->ptr, out->ld, (const TT*)y->ptr, y->ld, mean, scale,            \
                            (const float*)m12, (TT*)dy->ptr, dy->ld, (TT*)gpre->ptr, gpre->ld, slope, zero_far, y->d,  \
                            y->h, y->w, ca, y->c);                                                                     \
