@@ -219,6 +219,9 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
     const int64_t rrow_b = (int64_t)a.W * a.ldr * 2, rplane_b = (int64_t)a.H * rrow_b;
     char* ycur = nullptr;       // output row 0 of this wave's quarter in the plane being computed
     char* yprev = nullptr;      // ... in the plane whose epilogue is pending
+    // W % 32 == 16: the far 16-voxel half of the last column lies outside the volume - its wave computes on the zero
+    // halo and neither loads residual rows nor stores nor counts (wave-uniform flags, carried like ycur / yprev)
+    bool vcur = true, vprev = true;
     const char* rcur = nullptr;
     bool first = true;
 
@@ -245,27 +248,33 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
             if constexpr (HAS_STATS || HAS_RES || HAS_BST) {
                 const float v = (float)rv[i];                                      // the stored value of conv + bias
                 if constexpr (HAS_STATS) {
-                    st1[i] += v;
-                    st2[i] = fmaf(v, v, st2[i]);
+                    if (vprev) {
+                        st1[i] += v;
+                        st2[i] = fmaf(v, v, st2[i]);
+                    }
                 }
                 if constexpr (HAS_RES) ev[i] = v + (float)rq[p][i];
                 if constexpr (HAS_BST) {
                     const float o = (float)rq[p][i];                               // the activation lrelu(xhat)
                     const bool pos = o > 0.f;
                     const float gp = v * (pos ? 1.f : a.slope);
-                    st1[i] += gp;
-                    st2[i] = fmaf(gp, o * (pos ? 1.f : a.inv_slope), st2[i]);
+                    if (vprev) {
+                        st1[i] += gp;
+                        st2[i] = fmaf(gp, o * (pos ? 1.f : a.inv_slope), st2[i]);
+                    }
                 }
             }
         } else {
             char* dst = yprev + p * yrow_b + yvoff;
-            if constexpr (HAS_RES) {
-                f32x8 e;
+            if (vprev) {
+                if constexpr (HAS_RES) {
+                    f32x8 e;
 #pragma unroll
-                for (int i = 0; i < 8; i++) e[i] = ev[i];
-                *reinterpret_cast<bf16x8*>(dst) = __builtin_convertvector(e, bf16x8);
-            } else {
-                *reinterpret_cast<bf16x8*>(dst) = rv;
+                    for (int i = 0; i < 8; i++) e[i] = ev[i];
+                    *reinterpret_cast<bf16x8*>(dst) = __builtin_convertvector(e, bf16x8);
+                } else {
+                    *reinterpret_cast<bf16x8*>(dst) = rv;
+                }
             }
         }
     };
@@ -327,7 +336,12 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
         if constexpr (HAS_RES || HAS_BST)
             rcur = reinterpret_cast<const char*>(a.res + co_b) +
                    ((((int64_t)n * a.D + d0) * a.H + h0 + RH * hr) * a.W + w0 + 16 * hw) * (int64_t)a.ldr * 2;
-        if (first) yprev = ycur;
+        const bool vnext = w0 + 16 * hw < a.W;
+        if (first) {
+            yprev = ycur;
+            vprev = vnext;
+        }
+        vcur = vnext;
 
         // ---- activation fragment of pass q = (kd, kw) of the step with ring phase PHN: the wave's input row r
         auto frag_row = [&](auto phn, auto qc, auto rc) {
@@ -380,10 +394,12 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
                             if constexpr (w < 8) micro_b(std::integral_constant<int, PAR ^ 1>{}, std::integral_constant<int, 8 * p + w>{});
                             else micro_c(std::integral_constant<int, 10 * p + w - 8>{});
                         }
-                        if constexpr ((HAS_RES || HAS_BST) && q == NP - 1 && j % 3 == 1)
-                            rq[(j - 1) / 3] = *reinterpret_cast<const bf16x8*>(rcur + ((j - 1) / 3) * rrow_b + rvoff);
-                        if constexpr (HAS_X2 && q == 0 && j % 3 == 1)
-                            rq[(j - 1) / 3] = *reinterpret_cast<const bf16x8*>(rcur + ((j - 1) / 3) * rrow_b + xvoff);
+                        if constexpr ((HAS_RES || HAS_BST) && q == NP - 1 && j % 3 == 1) {
+                            if (vcur) rq[(j - 1) / 3] = *reinterpret_cast<const bf16x8*>(rcur + ((j - 1) / 3) * rrow_b + rvoff);
+                        }
+                        if constexpr (HAS_X2 && q == 0 && j % 3 == 1) {
+                            if (vcur) rq[(j - 1) / 3] = *reinterpret_cast<const bf16x8*>(rcur + ((j - 1) / 3) * rrow_b + xvoff);
+                        }
                     }
                     if constexpr (HAS_X2 && q == NP - 1 && j == NJ - 1) {
                         // the partner's tap: output row m <- its own row of the second tensor
@@ -399,6 +415,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
             SLIDE_STAMP(PH, 127, s)
             SLIDE_STAMP_RT(PH, 121, s)
             yprev = ycur;
+            vprev = vcur;
             ycur += yplane_b;
             if constexpr (HAS_RES || HAS_BST || HAS_X2) rcur += rplane_b;
         };
@@ -447,12 +464,12 @@ extern "C" void ru3d_debug_slide_stamps(long long* dev_buf) { g_slide_stamps = d
 // makespan on 256 CUs.
 bool slide_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* out) {
     static const int mode = getenv("RU3D_CONV_SLIDE") ? atoi(getenv("RU3D_CONV_SLIDE")) : 1;
-    if (mode == 0 || Cin != 32 || (Cout != 32 && Cout != 64) || (H % TH) || (W % TW) || D < 4) return false;
+    if (mode == 0 || Cin != 32 || (Cout != 32 && Cout != 64) || (H % TH) || (W % 16) || D < 4) return false;
     // the staging loads address a sample with 30-bit element offsets; the input may sit in a buffer of twice its channels
     // (the decoder's concat): shapes that could exceed that go to the other kernels consistently (launch, slab, workspace)
     if ((int64_t)D * H * W * Cin * 2 >= (1ll << 30)) return false;
     const int ny = Cout / 32;
-    const int64_t cols = (int64_t)N * (H / TH) * (W / TW);
+    const int64_t cols = (int64_t)N * (H / TH) * ((W + TW - 1) / TW);      // W % 32 == 16: the last column's far half idles
     int64_t best_cost = -1;
     int best = 0;
     for (int ds = 1; ds <= D / 4; ds++) {
@@ -478,7 +495,7 @@ bool slide_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* o
     out->dsplit = best;
     out->DL = D / best;
     out->tiles_h = H / TH;
-    out->tiles_w = W / TW;
+    out->tiles_w = (W + TW - 1) / TW;
     out->units = (int)units;
     int g = units < ru3d_get_cu_budget() / ny ? (int)units : ru3d_get_cu_budget() / ny;
     if ((units % 8) == 0 && g >= 8) g = (g / 8) * 8;

@@ -107,7 +107,10 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
 #pragma unroll
         for (int i = 0; i < NSD; i++) {
             const int f = (tid >> 2) + 64 * i;
-            dvoff[i] = (((h0 + f / TW) * a.W + w0 + f % TW) * a.lddy + cot * 32 + (tid & 3) * 8) * 2;
+            // a column of 32 may stick out of a W that is only a multiple of 16: those positions read zeros (no
+            // contribution), as the X halo does
+            dvoff[i] = (w0 + f % TW < a.W) ? (((h0 + f / TW) * a.W + w0 + f % TW) * a.lddy + cot * 32 + (tid & 3) * 8) * 2
+                                           : (int)0x80000000;
         }
         const bf16* xs = a.x + (int64_t)n * a.D * (xplane_b / 2);
         const bf16* ds = a.dy + (int64_t)n * a.D * (dplane_b / 2);
@@ -231,13 +234,13 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
 // units per pair = N x dsplit x (H/8) x (W/32); G persistent workgroups per pair (= slabs), pairs on grid.y.
 bool wgrad_slide_plan(const WgradGeom& g, WgradSlidePlan* out) {
     static const int mode = getenv("RU3D_WGRAD_SLIDE") ? atoi(getenv("RU3D_WGRAD_SLIDE")) : 1;
-    if (!mode || g.k != 3 || g.stride != 1 || (g.Cin % 32) || (g.Cout % 32) || (g.Ho % TH) || (g.Wo % TW)) return false;
+    if (!mode || g.k != 3 || g.stride != 1 || (g.Cin % 32) || (g.Cout % 32) || (g.Ho % TH) || (g.Wo % 16)) return false;
     if (g.Do != g.Di || g.Ho != g.Hi || g.Wo != g.Wi || (g.ldx % 8) || (g.lddy % 8)) return false;
     // buffer-descriptor byte offsets of a sample, the top bit marking "outside the volume"
     if ((int64_t)g.Do * g.Ho * g.Wo * (g.ldx > g.lddy ? g.ldx : g.lddy) >= (1ll << 30)) return false;
     const int pairs = (g.Cin / 32) * (g.Cout / 32);
     if (pairs > 8) return false;
-    const int64_t cols = (int64_t)g.N * (g.Ho / TH) * (g.Wo / TW);
+    const int64_t cols = (int64_t)g.N * (g.Ho / TH) * ((g.Wo + TW - 1) / TW);
     const int gmax = ru3d_get_cu_budget() / pairs;             // one workgroup per CU in total
     int64_t best_cost = -1;
     int best = 0;
@@ -260,7 +263,7 @@ bool wgrad_slide_plan(const WgradGeom& g, WgradSlidePlan* out) {
     out->dsplit = best;
     out->DL = g.Do / best;
     out->tiles_h = g.Ho / TH;
-    out->tiles_w = g.Wo / TW;
+    out->tiles_w = (g.Wo + TW - 1) / TW;
     out->units = (int)units;
     out->G = (int)(units < gmax ? units : gmax);
     out->pairs = pairs;

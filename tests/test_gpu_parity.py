@@ -438,6 +438,9 @@ def test_conv_with_channel_pitch_and_odd_extents(dtype):
                                    # more columns than workgroups: a workgroup finishes one column's last plane inside the
                                    # next column's first step, across a change of sample
                                    (6, 32, 32, 16, 64, 128), (5, 32, 64, 8, 64, 128),
+                                   # W = 16 mod 32 (config 4's 160 x 160 x 80): the sliding kernels' last column is half
+                                   # outside the volume - forward + residual, input gradient (32 -> 64 too), weight gradient
+                                   (2, 32, 32, 16, 64, 80), (2, 32, 64, 16, 64, 48), (2, 64, 32, 16, 64, 80),
                                    # deep-level shapes: the LDS-DMA weight gradient (two cout tiles per workgroup), ragged too
                                    (2, 128, 128, 16, 16, 16), (1, 256, 256, 8, 8, 8), (2, 128, 64, 9, 10, 20)])
 def test_mfma_conv_s1_bf16(shape):
@@ -554,7 +557,8 @@ def test_mfma_convtranspose_bf16(cin, cout, dims):
 @pytest.mark.parametrize("shape", [(2, 32, 32, 40, 36, 64), (1, 64, 64, 33, 40, 48), (3, 32, 64, 24, 24, 24),
                                    (1, 32, 32, 6, 6, 8), (2, 32, 32, 64, 64, 64), (5, 32, 32, 4, 128, 128),
                                    (3, 32, 32, 16, 64, 64), (2, 32, 64, 32, 64, 64), (2, 64, 64, 64, 64, 64),
-                                   (3, 64, 128, 12, 16, 64), (2, 64, 32, 32, 32, 64), (6, 32, 32, 16, 64, 128)])
+                                   (3, 64, 128, 12, 16, 64), (2, 64, 32, 32, 32, 64), (6, 32, 32, 16, 64, 128),
+                                   (2, 32, 32, 16, 64, 80)])      # W = 16 mod 32: the idle half column must not count
 def test_conv_fwd_in_fused_statistics(shape):
     """ru3d_conv3d_fwd_in: conv + InstanceNorm statistics.  On the persistent producer/consumer MFMA kernel the
     sums come from the conv epilogue; they must agree with a separate statistics pass over the stored output

@@ -156,7 +156,7 @@ if which in ("all", "k"):
         ok &= close(out, ref, 2 ** -8, "fused skip tail %s %s" % ((cin, cout), dims))
 if which in ("all", "d"):
     # decoder block: conv1 (k3 s1) + skip conv (k1 s1) input gradients in one launch (32 -> 64 / 32 channels)
-    for cin, cout, dims, n in [(64, 32, (16, 64, 64), 2), (32, 32, (8, 64, 128), 3), (64, 32, (32, 32, 64), 2)]:
+    for cin, cout, dims, n in [(64, 32, (16, 64, 64), 2), (32, 32, (8, 64, 128), 3), (64, 32, (32, 32, 64), 2), (64, 32, (16, 64, 80), 2)]:
         g = torch.Generator().manual_seed(cin + cout + sum(dims))
         d, h, w = dims
         xv = torch.randn(n, cin, d, h, w, generator=g)
