@@ -69,6 +69,8 @@ SIGNATURES = {
     "ru3d_conv3d_s2_dgrad_pair": (_i, [_P, _vp, _P, _vp, _P, _P, _i, _vp]),
     "ru3d_conv3d_wgrad_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),
     "ru3d_conv3d_wgrad": (_i, [_P, _P, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    "ru3d_wgrad_defer_begin": (_i, [_i]),
+    "ru3d_wgrad_defer_flush": (_i, [_i, _vp]),
     "ru3d_convtranspose3d_k3s2p1_fwd": (_i, [_P, _vp, _vp, _P, _i, _vp]),
     "ru3d_convtranspose3d_k3s2p1_fwd_in_workspace_bytes": (_sz, [_P, _P, _i]),
     "ru3d_convtranspose3d_k3s2p1_fwd_in": (_i, [_P, _vp, _vp, _P, _vp, _vp, _vp, _sz, _f, _i, _vp]),
@@ -259,9 +261,11 @@ def ptr(t):
 _WS = {}
 
 
-def workspace(nbytes, device):
-    """One growing scratch buffer per (device, stream): every kernel that uses it runs in-order on that stream."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+def workspace(nbytes, device, slot=0):
+    """One growing scratch buffer per (device, stream[, slot]): every kernel that uses it runs in-order on that stream.
+    slot > 0: a buffer of its own for scratch that must outlive the next kernels (deferred weight-gradient slabs)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream) if slot == 0 else \
+        (device, torch.cuda.current_stream(device).cuda_stream, slot)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

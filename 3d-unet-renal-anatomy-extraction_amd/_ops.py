@@ -282,13 +282,46 @@ def _grad_out(key, shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
-def conv_wgrad(x, dy, k, stride, key=None):
+class DeferredWgrads:
+    """`with DeferredWgrads(dtype, device) as d:` - the weight gradients computed inside (conv_wgrad(..., defer=d)) run
+    their main kernels at once and their fixed-order slab sums as ONE launch on exit (ru3d_wgrad_defer_begin / _flush):
+    a ResBlock's two or three 12-18 us sums overlap instead of queueing.  Every deferred call gets a workspace of its
+    own, kept alive until the flush."""
+
+    def __init__(self, dtype, device, enable=True):
+        self.code = N.dtype_code(dtype)
+        self.device = device
+        self.enable = enable
+        self.keep = []
+
+    def __enter__(self):
+        if self.enable:
+            N.note_device(self.device)
+            check(N.lib.ru3d_wgrad_defer_begin(self.code), "wgrad_defer_begin")
+        return self
+
+    def __exit__(self, *exc):
+        if self.enable:
+            N.note_device(self.device)
+            rc = N.lib.ru3d_wgrad_defer_flush(self.code, stream())      # always: the library must leave the deferred mode
+            self.keep = []
+            if exc[0] is None:
+                check(rc, "wgrad_defer_flush")
+        return False
+
+    def scratch(self, nbytes):
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+        self.keep.append(buf)
+        return buf
+
+
+def conv_wgrad(x, dy, k, stride, key=None, defer=None):
     cout, cin = dy.shape[1], x.shape[1]
     dw = _grad_out(key, (cout, cin, k, k, k), x.device)
     dx, ddy = desc(x), desc(dy)
     code = N.dtype_code(x.dtype)
     nbytes = N.lib.ru3d_conv3d_wgrad_workspace_bytes(ref(dx), ref(ddy), k, stride, code)
-    ws = N.workspace(nbytes, x.device)
+    ws = defer.scratch(nbytes) if (defer is not None and defer.enable) else N.workspace(nbytes, x.device)
     check(N.lib.ru3d_conv3d_wgrad(ref(dx), ref(ddy), ptr(dw), ptr(ws), ws.numel(), k, stride, code, stream()),
           "conv3d_wgrad")
     return dw
@@ -619,6 +652,7 @@ def as_grad(g, like_dtype):
 # gradients on the main stream.  Off by default (RU3D_WGRAD_STREAM=1 enables): at ~550 launches per 28 ms step the extra stream switches cost
 # the host more than the overlap returns; it is kept for graph-captured steps.
 _USE_SIDE = os.environ.get("RU3D_WGRAD_STREAM", "0") == "1"
+_DEFER_WGRAD = os.environ.get("RU3D_WGRAD_DEFER", "0") == "1"      # measured: no gain (the sums are work, not launch latency)
 _SIDE = {}
 
 
@@ -849,10 +883,25 @@ class ResBlockFn(torch.autograd.Function):
         dy2, gpre, gbs_sum = in_lrelu_bwd(gz, z, y2, mean2, scale2, want_gpre=True, want_gpre_sum=True)
         del y2
         gws = gbs = None
+        # the block's two or three slab sums go out as one launch at the end (not with padded channels: the un-padding
+        # reads the gradient right away; not on the side stream: begin / flush bracket one stream)
+        defer = DeferredWgrads(sd, dev, enable=not (cout_seg or cin_seg) and not _USE_SIDE and _DEFER_WGRAD)
+        defer.__enter__()
+        try:
+            return ResBlockFn._backward_tail(ctx, defer, x, a1, y1, dy2, gpre, gbs_sum, mean1, scale1, pw2d, pw1d, pwsd)
+        finally:
+            defer.__exit__(*__import__("sys").exc_info())
+
+    @staticmethod
+    def _backward_tail(ctx, defer, x, a1, y1, dy2, gpre, gbs_sum, mean1, scale1, pw2d, pw1d, pwsd):
+        cout, cin, cout_seg, cin_seg = ctx.dims
+        dev = x.device
+        stride = ctx.stride
+        gws = gbs = None
         with _OnSide(dev):
-            gw2 = unpad_wgrad(conv_wgrad(a1, dy2, 3, 1, key=ctx.wkeys[1]), cout, cout, cout_seg, cout_seg)
+            gw2 = unpad_wgrad(conv_wgrad(a1, dy2, 3, 1, key=ctx.wkeys[1], defer=defer), cout, cout, cout_seg, cout_seg)
             if ctx.has_skip_conv:
-                gws = unpad_wgrad(conv_wgrad(x, gpre, 1, stride, key=ctx.wkeys[2]), cout, cin, cout_seg, cin_seg)
+                gws = unpad_wgrad(conv_wgrad(x, gpre, 1, stride, key=ctx.wkeys[2], defer=defer), cout, cin, cout_seg, cin_seg)
                 gbs = gbs_sum[:cout]
         gb2 = None   # a bias that feeds InstanceNorm has an identically zero gradient: reported as "no gradient"
         # conv2's input gradient and the IN1 + LeakyReLU backward in one call: on the sliding-kernel shapes the backward's
@@ -860,7 +909,7 @@ class ResBlockFn(torch.autograd.Function):
         dy1 = conv_dgrad_in_bwd(dy2, pw2d, a1, mean1, scale1)
         del dy2, a1, y1
         with _OnSide(dev):
-            gw1 = unpad_wgrad(conv_wgrad(x, dy1, 3, stride, key=ctx.wkeys[0]), cout, cin, cout_seg, cin_seg)
+            gw1 = unpad_wgrad(conv_wgrad(x, dy1, 3, stride, key=ctx.wkeys[0], defer=defer), cout, cin, cout_seg, cin_seg)
         gb1 = None
         gx = None
         need_gx = ctx.needs_input_grad[0]

@@ -558,6 +558,17 @@ extern "C" int ru3d_conv3d_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, fl
     return wgrad_generic_launch(x->ptr, dy->ptr, dw, ws, ws_bytes, g, dtype, as_stream(stream));
 }
 
+extern "C" int ru3d_wgrad_defer_begin(int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_wgrad_defer_begin_f16(dtype));
+    return wgrad_defer_begin();
+}
+
+extern "C" int ru3d_wgrad_defer_flush(int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_wgrad_defer_flush_f16(dtype, stream));
+    Ru3dDeviceGuard dev_guard(stream);
+    return wgrad_defer_flush(as_stream(stream));
+}
+
 // --------------------------------------------------------------------------- ConvTranspose3d(k3,s2,p1) + far pad
 static bool convt_shapes_ok(const ru3d_tensor* x, const ru3d_tensor* y) {
     return tensor_ok(x) && tensor_ok(y) && x->n == y->n && y->d == 2 * x->d && y->h == 2 * x->h && y->w == 2 * x->w;

@@ -69,6 +69,9 @@ int pack_generic_launch(const float* src, void* dst, int cin, int cout, int taps
 size_t wgrad_generic_ws_bytes(const WgradGeom& g);
 int wgrad_reduce_launch(const float* part, float* dw, int chunks, int taps, int cin, int cout, int64_t s_o, int64_t s_i,
                         hipStream_t st);
+// deferred slab sums: between begin and flush wgrad_reduce_launch only records its arguments (thread-local)
+int wgrad_defer_begin();
+int wgrad_defer_flush(hipStream_t st);
 int wgrad_generic_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, WgradGeom g, int dtype,
                          hipStream_t st);
 

@@ -505,13 +505,12 @@ __global__ __launch_bounds__(256) void wgrad_generic_kernel(const T* __restrict_
 // dw[co*s_o + ci*s_i + tap] = sum_chunk part[chunk][tap][ci][co]
 // block = 64 x (4 consecutive outputs, one 16-byte load) x 4 chunk lanes; each lane keeps 4 independent
 // slab loads in flight; the 4 lane sums are combined in a fixed order -> deterministic.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                           int chunks, int taps, int cin, int cout, int64_t s_o,
-                                                           int64_t s_i) {
-    __shared__ f32x4 sh[4][64];
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, float* __restrict__ dw, int chunks,
+                                                  int taps, int cin, int cout, int64_t s_o, int64_t s_i, int bid,
+                                                  f32x4 (*sh)[64]) {
     const int64_t total = (int64_t)taps * cin * cout;   // multiple of 4 is NOT required: tail handled scalar
     const int ox = threadIdx.x & 63, ky = threadIdx.x >> 6;
-    const int64_t i0 = ((int64_t)blockIdx.x * 64 + ox) * 4;
+    const int64_t i0 = ((int64_t)bid * 64 + ox) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     const bool full = (i0 + 3 < total) && ((total & 3) == 0);
     if (full) {
@@ -546,17 +545,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           int chunks, int taps, int cin, int cout, int64_t s_o,
+                                                           int64_t s_i) {
+    __shared__ f32x4 sh[4][64];
+    wgrad_reduce_body(part, dw, chunks, taps, cin, cout, s_o, s_i, blockIdx.x, sh);
+}
+
 // The same sum for the wide layers (Cin*Cout >= 128*128: few slabs, megabytes each), where the write side
 // matters: slabs are [tap][ci][co] but dw is [co][ci][tap] (Conv3d) or [ci][co][tap] (ConvTranspose3d), so the
 // kernel above stores 4 bytes per 108-byte stride.  Here a block owns all taps of a (4 ci) x (32 co) tile, sums
 // the slabs in slab order (deterministic) with 128-byte row reads, transposes through LDS and writes runs of
 // 4*taps (CO_MAJOR, Conv3d) or 32*taps (ConvTranspose3d) consecutive floats.
 template <bool CO_MAJOR>
-__global__ __launch_bounds__(256) void wgrad_reduce_tiled_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                 int chunks, int taps, int cin, int cout, int64_t s_o,
-                                                                 int64_t s_i) {
-    __shared__ float tile[32 * (4 * 27 + 1)];
-    const int cot = blockIdx.x % (cout / 32), cit = blockIdx.x / (cout / 32);
+__device__ __forceinline__ void wgrad_reduce_tiled_body(const float* __restrict__ part, float* __restrict__ dw, int chunks,
+                                                        int taps, int cin, int cout, int64_t s_o, int64_t s_i, int bid,
+                                                        float* tile) {
+    const int cot = bid % (cout / 32), cit = bid / (cout / 32);
     const int ci0 = cit * 4, co0 = cot * 32;
     const int64_t total = (int64_t)taps * cin * cout;
     const int nquads = taps * 32;   // (tap, ci_l, co4)
@@ -598,22 +603,97 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tiled_kernel(const float* __
     }
 }
 
+template <bool CO_MAJOR>
+__global__ __launch_bounds__(256) void wgrad_reduce_tiled_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                 int chunks, int taps, int cin, int cout, int64_t s_o,
+                                                                 int64_t s_i) {
+    __shared__ float tile[32 * (4 * 27 + 1)];
+    wgrad_reduce_tiled_body<CO_MAJOR>(part, dw, chunks, taps, cin, cout, s_o, s_i, blockIdx.x, tile);
+}
+
+// Several slab sums in ONE launch (ru3d_wgrad_defer_begin / _flush): a ResBlock's backward produces two or three weight
+// gradients whose slab sums are 12-18 us launches each - latency, not bandwidth; issued together they overlap.
+struct WgradReduceItem {
+    const float* part;
+    float* dw;
+    int chunks, taps, cin, cout;
+    int64_t s_o, s_i;
+    int kind;          // 0: plain, 1: tiled CO_MAJOR, 2: tiled CI_MAJOR
+    int block_base;    // first block of the item in the merged grid
+};
+#define RU3D_DEFER_MAX 8
+struct WgradReduceBatch {
+    int count;
+    WgradReduceItem item[RU3D_DEFER_MAX];
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgradReduceBatch b) {
+    __shared__ float tile[32 * (4 * 27 + 1)];
+    __shared__ f32x4 sh[4][64];
+    int i = 0;
+    while (i + 1 < b.count && (int)blockIdx.x >= b.item[i + 1].block_base) i++;
+    const WgradReduceItem& it = b.item[i];
+    const int bid = blockIdx.x - it.block_base;
+    if (it.kind == 0) wgrad_reduce_body(it.part, it.dw, it.chunks, it.taps, it.cin, it.cout, it.s_o, it.s_i, bid, sh);
+    else if (it.kind == 1) wgrad_reduce_tiled_body<true>(it.part, it.dw, it.chunks, it.taps, it.cin, it.cout, it.s_o, it.s_i, bid, tile);
+    else wgrad_reduce_tiled_body<false>(it.part, it.dw, it.chunks, it.taps, it.cin, it.cout, it.s_o, it.s_i, bid, tile);
+}
+
+static thread_local struct {
+    bool on = false;
+    WgradReduceBatch batch;
+    int blocks = 0;
+} g_defer;
+
+static int wgrad_reduce_flush(hipStream_t st) {
+    if (g_defer.batch.count == 0) return 0;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)g_defer.blocks), dim3(256), 0, st, g_defer.batch);
+    g_defer.batch.count = 0;
+    g_defer.blocks = 0;
+    return ru3d_check_launch("wgrad_reduce_multi");
+}
+
+int wgrad_defer_begin() {
+    g_defer.on = true;
+    g_defer.batch.count = 0;
+    g_defer.blocks = 0;
+    return 0;
+}
+
+int wgrad_defer_flush(hipStream_t st) {
+    g_defer.on = false;
+    return wgrad_reduce_flush(st);
+}
+
 int wgrad_reduce_launch(const float* part, float* dw, int chunks, int taps, int cin, int cout, int64_t s_o, int64_t s_i,
                         hipStream_t st) {
     const int64_t total = (int64_t)taps * cin * cout;
-    if ((int64_t)cin * cout >= 128 * 128 && (cin % 4) == 0 && (cout % 32) == 0 && taps <= 27 &&
-        (s_i == taps || s_o == taps)) {
-        const unsigned blocks = (unsigned)((cin / 4) * (cout / 32));
+    const bool tiled = (int64_t)cin * cout >= 128 * 128 && (cin % 4) == 0 && (cout % 32) == 0 && taps <= 27 &&
+                       (s_i == taps || s_o == taps);
+    const int64_t blocks = tiled ? (int64_t)(cin / 4) * (cout / 32) : (total + 255) / 256;
+    if (blocks > 0x3fffffff) return ru3d_fail(-1, "wgrad_reduce: grid too large");
+    if (g_defer.on) {
+        // the slabs stay where they are until the flush: the caller gave every deferred weight gradient its own workspace
+        if (g_defer.batch.count == RU3D_DEFER_MAX || (int64_t)g_defer.blocks + blocks > 0x3fffffff) {
+            int rc = wgrad_reduce_flush(st);
+            if (rc) return rc;
+        }
+        WgradReduceItem& it = g_defer.batch.item[g_defer.batch.count++];
+        it.part = part; it.dw = dw; it.chunks = chunks; it.taps = taps; it.cin = cin; it.cout = cout; it.s_o = s_o; it.s_i = s_i;
+        it.kind = tiled ? (s_i == taps ? 1 : 2) : 0;
+        it.block_base = g_defer.blocks;
+        g_defer.blocks += (int)blocks;
+        return 0;
+    }
+    if (tiled) {
         if (s_i == taps)
-            hipLaunchKernelGGL(wgrad_reduce_tiled_kernel<true>, dim3(blocks), dim3(256), 0, st, part, dw, chunks, taps,
+            hipLaunchKernelGGL(wgrad_reduce_tiled_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, part, dw, chunks, taps,
                                cin, cout, s_o, s_i);
         else
-            hipLaunchKernelGGL(wgrad_reduce_tiled_kernel<false>, dim3(blocks), dim3(256), 0, st, part, dw, chunks, taps,
+            hipLaunchKernelGGL(wgrad_reduce_tiled_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, part, dw, chunks, taps,
                                cin, cout, s_o, s_i);
         return ru3d_check_launch("wgrad_reduce_tiled");
     }
-    const int64_t blocks = (total + 255) / 256;
-    if (blocks > 0x7fffffff) return ru3d_fail(-1, "wgrad_reduce: grid too large");
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, dw, chunks, taps, cin, cout,
                        s_o, s_i);
     return ru3d_check_launch("wgrad_reduce");

@@ -239,7 +239,8 @@ bool wgrad_slide_plan(const WgradGeom& g, WgradSlidePlan* out) {
     // buffer-descriptor byte offsets of a sample, the top bit marking "outside the volume"
     if ((int64_t)g.Do * g.Ho * g.Wo * (g.ldx > g.lddy ? g.ldx : g.lddy) >= (1ll << 30)) return false;
     const int pairs = (g.Cin / 32) * (g.Cout / 32);
-    if (pairs > 8) return false;
+    static const int max_pairs = getenv("RU3D_WGRAD_SLIDE_PAIRS") ? atoi(getenv("RU3D_WGRAD_SLIDE_PAIRS")) : 16;
+    if (pairs > max_pairs) return false;
     const int64_t cols = (int64_t)g.N * (g.Ho / TH) * ((g.Wo + TW - 1) / TW);
     const int gmax = ru3d_get_cu_budget() / pairs;             // one workgroup per CU in total
     int64_t best_cost = -1;

@@ -151,6 +151,13 @@ size_t ru3d_conv3d_wgrad_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor
 int ru3d_conv3d_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, float* dw, void* ws, size_t ws_bytes,
                       int k, int stride, int dtype, void* stream);
 
+/* Several weight gradients whose slab sums go out as ONE launch: between `begin` and `flush` (same host thread, same
+ * stream, same dtype) every ru3d_conv3d_wgrad / ru3d_convtranspose3d_k3s2p1_wgrad call runs its main kernel at once but
+ * only records its fixed-order slab sum; `flush` issues the recorded sums together.  The caller must give every
+ * deferred call its OWN workspace (the slabs live there until the flush) and must not read dw before the flush. */
+int ru3d_wgrad_defer_begin(int dtype);
+int ru3d_wgrad_defer_flush(int dtype, void* stream);
+
 /* nn.ConvTranspose3d(k3,s2,p1) followed by ConstantPad3d((0,1,0,1,0,1),0) (network.py:312-314):
  * y has extents 2*x.{d,h,w}; its far planes are written as exact zeros (no bias there). */
 int ru3d_convtranspose3d_k3s2p1_fwd(const ru3d_tensor* x, const void* w_packed, const float* bias,
