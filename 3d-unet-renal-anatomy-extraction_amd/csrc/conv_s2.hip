@@ -738,9 +738,9 @@ static bool t_plan(int N, int Di, int Hi, int Wi, int Cin, int Cout, int* tw_out
     const int ny = Cout / 32;
     int64_t best_cost = -1;
     int best_ds = 0, best_tw = 0;
-    static const int force_tw = getenv("RU3D_S2_TW") ? atoi(getenv("RU3D_S2_TW")) : 0;
-    for (int tw = 16; tw <= 32; tw += 16) {
-        if (force_tw && tw != force_tw) continue;
+    // 16-wide tiles only: the 32-wide instantiation (half the halo rows per voxel) measured slower on the same box - its
+    // consumers spill and a step carries twice the work between barriers (189 vs 148 us, 103 vs 97 us at 64^3 -> 128^3)
+    for (int tw = 16; tw <= 16; tw += 16) {
         const int64_t cols = (int64_t)N * ((Hi + TH - 1) / TH) * ((Wi + tw - 1) / tw);
         for (int ds = 1; ds <= Di; ds++) {
             const int dl = (Di + ds - 1) / ds;
@@ -856,7 +856,7 @@ int convt_s2_tile_launch(const void* x, const void* w, const float* bias, const 
     a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w; a.dsplit = p.dsplit; a.DL = p.DL; a.units = p.units;
     static const int dbg = getenv("RU3D_S2_DBG") ? atoi(getenv("RU3D_S2_DBG")) : 0;
     a.dbg = dbg;
-    if (tw == 32) return t_launch<64, 32>(a, p, res != nullptr, stat_slab != nullptr, x2 != nullptr, st);
+    (void)tw;
     return t_launch<64, 16>(a, p, res != nullptr, stat_slab != nullptr, x2 != nullptr, st);
 }
 

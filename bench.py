@@ -397,7 +397,20 @@ def main():
     out["roofline_step"] = {"alg_flops": sflops, "alg_bytes": sbytes, "achieved_tflops": sflops / t_step / 1e12,
                             "frac_mfma": sflops / t_step / peak_f, "achieved_gbps": sbytes / t_step / 1e9,
                             "frac_hbm": sbytes / t_step / HBM_PEAK, "peak_tflops": peak_f / 1e12,
-                            "bound_ms": 1e3 * max(sflops / peak_f, sbytes / HBM_PEAK)}
+                            "bound_ms": 1e3 * max(sflops / peak_f, sbytes / HBM_PEAK), "traffic": None}
+    # HBM bytes one step really moves: two PMC passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_step.sh) over this very
+    # configuration, committed under profiles/ - the figure is only attached to the shape it was measured on
+    try:
+        if elem == 2 and cube and dims[0] == 128 and args.batch == 2 and args.features == 32 and args.pools == 4:
+            steps_pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_step_traffic.json"))
+            if steps_pmc:
+                t = json.load(open(os.path.join(ROOT, "profiles", steps_pmc[-1])))
+                out["roofline_step"]["traffic"] = t["hbm_bytes_per_step"]
+                out["roofline_step"]["traffic_over_alg_bytes"] = t["hbm_bytes_per_step"] / sbytes
+                out["roofline_step"]["traffic_hbm_ms"] = 1e3 * t["hbm_bytes_per_step"] / HBM_PEAK
+                out["roofline_step"]["traffic_source"] = "profiles/" + steps_pmc[-1]
+    except Exception:
+        pass
     if probe is not None:
         n_launch, mean_ms = probe.result()
         v = vox_per_step
