@@ -46,6 +46,7 @@ PACK_MAX = 12
 _P = ctypes.POINTER(Tensor)
 _vp, _i, _i64, _f, _sz, _u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t,
                                 ctypes.c_uint64)
+_dbl = ctypes.c_double
 
 # name -> (restype, argtypes): every symbol include/ru3d.h declares
 SIGNATURES = {
@@ -87,6 +88,11 @@ SIGNATURES = {
     "ru3d_conv3d_dgrad_in_bwd_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),
     "ru3d_conv3d_dgrad_in_bwd": (_i, [_P, _vp, _P, _vp, _vp, _P, _P, _i, _i, _f, _i, _vp, _sz, _vp]),
     "ru3d_channel_sum": (_i, [_P, _vp, _vp, _sz, _i, _vp]),
+    "ru3d_batchnorm_stats_pool": (_i, [_P, _vp, _vp, _vp, _sz, _i, _vp]),
+    "ru3d_batchnorm_stats_finalize": (_i, [_vp, _i, _i, _i, _dbl, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ru3d_affine_lrelu_fwd": (_i, [_P, _vp, _vp, _P, _P, _f, _i, _vp]),
+    "ru3d_batchnorm_bwd_pool": (_i, [_P, _P, _P, _vp, _vp, _P, _vp, _vp, _sz, _f, _i, _vp]),
+    "ru3d_batchnorm_bwd_apply": (_i, [_P, _P, _vp, _vp, _vp, _vp, _dbl, _P, _vp, _sz, _i, _i, _vp]),
     "ru3d_dropout3d_scale": (_i, [_vp, _i, _f, _u64, _u64, _vp]),
     "ru3d_dropout3d_scale_dev": (_i, [_vp, _i, _f, _u64, _u64, _vp, _vp]),
     "ru3d_pointwise": (_i, [_i, _P, _P, _P, _P, _P, _f, _i, _vp]),

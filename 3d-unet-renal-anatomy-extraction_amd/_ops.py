@@ -483,6 +483,91 @@ def in_lrelu_bwd(gout, out, y, mean, scale, want_gpre=False, zero_far=False, wan
     return dy, gpre
 
 
+# --------------------------------------------------------------------------- BatchNorm3d, training mode
+_BN_SYNC = [None, 1]     # (process group or None, world size): set_bn_sync
+
+
+def set_bn_sync(group=None, enable=True):
+    """SyncBN: pool the BatchNorm sums of every rank of `group` (None = the default group) in both directions.
+    Off by default - the reference's nn.DataParallel normalises each replica's sub-batch on its own (trainer.py:531-535)."""
+    import torch.distributed as dist
+    if enable and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        _BN_SYNC[0], _BN_SYNC[1] = (group if group is not None else dist.group.WORLD), dist.get_world_size(group)
+    else:
+        _BN_SYNC[0], _BN_SYNC[1] = None, 1
+
+
+def _bn_allreduce(pooled):
+    if _BN_SYNC[0] is not None:
+        import torch.distributed as dist
+        dist.all_reduce(pooled, group=_BN_SYNC[0])
+    return pooled
+
+
+def bn_train_stats(y, drop_scale, norm, c_real):
+    """Batch statistics of `y` (with Dropout3d's factors folded in), the running averages of `norm` moved (reference
+    nn.BatchNorm3d defaults, network.py:38-69) -> (fscale, fshift, a, b, count): out = lrelu(y * fscale + fshift),
+    x_hat = y * a + b.  c_real: the module's channel count (y may carry zero pad lanes beyond it)."""
+    n, c = y.shape[0], y.shape[1]
+    dev = y.device
+    dy = desc(y)
+    pooled = torch.empty(2 * c, dtype=torch.float64, device=dev)
+    ws = N.workspace(N.lib.ru3d_reduce_workspace_bytes(ref(dy)), dev)
+    check(N.lib.ru3d_batchnorm_stats_pool(ref(dy), ptr(drop_scale), ptr(pooled), ptr(ws), ws.numel(),
+                                          N.dtype_code(y.dtype), stream()), "batchnorm_stats_pool")
+    _bn_allreduce(pooled)
+    count = float(n * y.shape[2] * y.shape[3] * y.shape[4]) * _BN_SYNC[1]
+    track = norm.track_running_stats and norm.running_mean is not None
+    momentum = 0.0
+    if track:
+        norm.num_batches_tracked.add_(1)
+        momentum = (1.0 / float(norm.num_batches_tracked)) if norm.momentum is None else float(norm.momentum)
+    out = torch.empty(4, n * c, dtype=torch.float32, device=dev)
+    gamma = norm.weight.detach() if norm.weight is not None else None
+    beta = norm.bias.detach() if norm.bias is not None else None
+    for t in (gamma, beta, norm.running_mean if track else None, norm.running_var if track else None):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev):
+            raise N.Ru3dError("BatchNorm3d: parameters / running statistics must be contiguous fp32 on %s" % dev)
+    check(N.lib.ru3d_batchnorm_stats_finalize(ptr(pooled), n, c, c_real, count, ptr(drop_scale), ptr(gamma), ptr(beta),
+                                              float(norm.eps), momentum, ptr(norm.running_mean if track else None),
+                                              ptr(norm.running_var if track else None), ptr(out[0]), ptr(out[1]),
+                                              ptr(out[2]), ptr(out[3]), stream()), "batchnorm_stats_finalize")
+    return out[0], out[1], out[2], out[3], count
+
+
+def affine_lrelu_fwd(y, scale, shift, res=None, out=None):
+    if out is None:
+        n, c, d, h, w = y.shape
+        out = N.new_act(n, c, d, h, w, y.dtype, y.device)
+    dy, do = desc(y), desc(out)
+    dr = desc(res) if res is not None else None
+    check(N.lib.ru3d_affine_lrelu_fwd(ref(dy), ptr(scale), ptr(shift), ref(dr), ref(do), LRELU_SLOPE,
+                                      N.dtype_code(y.dtype), stream()), "affine_lrelu_fwd")
+    return out
+
+
+def bn_lrelu_bwd(gout, out, y, a, b, fscale, count, zero_far=False):
+    """Backward of out = lrelu(BN(y) (+ res)): -> dy, gpre (= dL/dres), dgamma, dbeta (this rank's sums, padded width)."""
+    n, c, d, h, w = y.shape
+    dev = y.device
+    dy = N.new_act(n, c, d, h, w, y.dtype, dev)
+    gpre = N.new_act(n, c, d, h, w, y.dtype, dev)
+    dg, do, dyy, ddy, dp = desc(gout), desc(out), desc(y), desc(dy), desc(gpre)
+    pooled = torch.empty(2 * c, dtype=torch.float64, device=dev)
+    ws = N.workspace(N.lib.ru3d_reduce_workspace_bytes(ref(dyy)), dev)
+    code = N.dtype_code(y.dtype)
+    check(N.lib.ru3d_batchnorm_bwd_pool(ref(dg), ref(do), ref(dyy), ptr(a), ptr(b), ref(dp), ptr(pooled), ptr(ws),
+                                        ws.numel(), LRELU_SLOPE, code, stream()), "batchnorm_bwd_pool")
+    local = pooled.view(c, 2).to(torch.float32)
+    dbeta, dgamma = local[:, 0].contiguous(), local[:, 1].contiguous()
+    if _BN_SYNC[0] is not None:
+        pooled = _bn_allreduce(pooled.clone())
+    check(N.lib.ru3d_batchnorm_bwd_apply(ref(dp), ref(dyy), ptr(a), ptr(b), ptr(fscale), ptr(pooled), float(count),
+                                         ref(ddy), ptr(ws), ws.numel(), 1 if zero_far else 0, code, stream()),
+          "batchnorm_bwd_apply")
+    return dy, gpre, dgamma, dbeta
+
+
 def channel_sum(t):
     out = torch.empty(t.shape[1], dtype=torch.float32, device=t.device)
     dt = desc(t)
@@ -1007,6 +1092,149 @@ class UpFn(torch.autograd.Function):
         if ctx.link is not None and gskip is not None:
             ctx.link.grad, gskip = gskip, None       # added by the pooling block's input-gradient kernel (SkipLink)
         return gx, gw, gb, gskip, None, None
+
+
+# --------------------------------------------------------------------------- autograd: BatchNorm blocks, training mode
+class ResBlockBNFn(torch.autograd.Function):
+    """ResBlock built with norm_op=nn.BatchNorm3d (reference network.py:38-69, 405-416) in training mode:
+        skip = skip_conv(x) | x;  x = conv1(x); x = dropout(x); x = lrelu(BN(x)); x = conv2(x); lrelu(BN(x) + skip)
+    with the block's ONE BatchNorm3d module used twice (network.py:401: both calls move the running averages, in this
+    order; gamma / beta gradients are the sum of the two uses).  Same kernels as ResBlockFn around the batch-pooled
+    statistics (bn_train_stats / bn_lrelu_bwd); `norm` is the module (running buffers are updated in place)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, ws, bs, gamma, beta, stride, drop_scale, pad, norm):
+        sd = x.dtype
+        x = N.to_ndhwc(x)
+        cout, cin = w1.shape[0], w1.shape[1]
+        cin_seg = seg_of(cin, x.shape[1], int(pad)) if pad else 0
+        cout_seg = cout if pad else 0
+        if not pad and x.shape[1] != cin:
+            raise N.Ru3dError("ResBlock: input has %d channels, conv1 expects %d" % (x.shape[1], cin))
+        cout_p = padded_dim(cout, cout_seg)
+        need_gx = ctx.needs_input_grad[0]
+        specs = [(w1, N.ROLE_CONV_FWD, stride, cout_seg, cin_seg), (w2, N.ROLE_CONV_FWD, 1, cout_seg, cout_seg)]
+        if ws is not None:
+            specs.append((ws, N.ROLE_CONV_FWD, stride, cout_seg, cin_seg))
+        nfwd = len(specs)
+        specs.append((w2, N.ROLE_CONV_DGRAD, 1, cout_seg, cout_seg))
+        if need_gx:
+            specs.append((w1, N.ROLE_CONV_DGRAD, stride, cout_seg, cin_seg))
+            if ws is not None:
+                specs.append((ws, N.ROLE_CONV_DGRAD, stride, cout_seg, cin_seg))
+        nw = len(specs)
+        if cout_seg:
+            specs += [(b, N.ROLE_BIAS, 1, cout_seg, 0) for b in (b1, b2, bs) if b is not None]
+        packs = pack_weights(specs, sd)
+        has_b = (b1 is not None, b2 is not None, bs is not None)
+        if cout_seg:
+            it = iter(packs[nw:])
+            b1, b2, bs = [(_f32_view(next(it), cout_p) if b is not None else None) for b in (b1, b2, bs)]
+        y1 = conv_fwd(x, packs[0], b1, cout_p, 3, stride)
+        fs1, fh1, a1s, b1s, cnt1 = bn_train_stats(y1, drop_scale, norm, cout)
+        a1 = affine_lrelu_fwd(y1, fs1, fh1)
+        y2 = conv_fwd(a1, packs[1], b2, cout_p, 3, 1)
+        fs2, fh2, a2s, b2s, cnt2 = bn_train_stats(y2, None, norm, cout)
+        skip = conv_fwd(x, packs[2], bs, cout_p, 1, stride) if ws is not None else x
+        z = affine_lrelu_fwd(y2, fs2, fh2, res=skip)
+        bwd = packs[nfwd:nw] + [None] * 3
+        ctx.save_for_backward(x, y1, a1, y2, z, fs1, a1s, b1s, fs2, a2s, b2s, bwd[0], bwd[1], bwd[2])
+        ctx.dims = (cout, cin, cout_seg, cin_seg)
+        ctx.counts = (cnt1, cnt2)
+        ctx.stride = stride
+        ctx.has_skip_conv = ws is not None
+        ctx.has_b = has_b
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, y1, a1, y2, z, fs1, a1s, b1s, fs2, a2s, b2s, pw2d, pw1d, pwsd = ctx.saved_tensors
+        cout, cin, cout_seg, cin_seg = ctx.dims
+        stride = ctx.stride
+        gz = as_grad(gz, x.dtype)
+        dy2, gpre, dg2, db2 = bn_lrelu_bwd(gz, z, y2, a2s, b2s, fs2, ctx.counts[1])
+        gw2 = unpad_wgrad(conv_wgrad(a1, dy2, 3, 1), cout, cout, cout_seg, cout_seg)
+        gb2 = channel_sum(dy2)[:cout] if ctx.has_b[1] else None
+        gws = gbs = None
+        if ctx.has_skip_conv:
+            gws = unpad_wgrad(conv_wgrad(x, gpre, 1, stride), cout, cin, cout_seg, cin_seg)
+            gbs = db2[:cout].clone() if ctx.has_b[2] else None        # sum of gpre over n and voxels
+        da1 = conv_dgrad(dy2, pw2d, tuple(a1.shape), 3, 1)
+        del dy2
+        dy1, _, dg1, db1 = bn_lrelu_bwd(da1, a1, y1, a1s, b1s, fs1, ctx.counts[0])
+        del da1
+        gw1 = unpad_wgrad(conv_wgrad(x, dy1, 3, stride), cout, cin, cout_seg, cin_seg)
+        # with Dropout3d between conv1 and a BATCH norm the bias does not cancel (its share d[n][c] * b differs per sample)
+        gb1 = channel_sum(dy1)[:cout] if ctx.has_b[0] else None
+        gx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.has_skip_conv:
+                gx0 = conv_dgrad(gpre, pwsd, tuple(x.shape), 1, stride)
+                gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gx0)
+            else:
+                gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gpre)
+        ggamma = (dg1 + dg2)[:cout] if ctx.needs_input_grad[7] else None
+        gbeta = (db1 + db2)[:cout] if ctx.needs_input_grad[8] else None
+        return gx, gw1, gb1, gw2, gb2, gws, gbs, ggamma, gbeta, None, None, None, None
+
+
+class UpBNFn(torch.autograd.Function):
+    """ConvTrans3D built with norm_op=nn.BatchNorm3d in training mode (reference network.py:311-317, + :346-350 when
+    `skip` is given): u = lrelu(BN(pad_far(convT_k3s2p1(x)))); return cat((u, skip), dim=1).  The zero far planes are
+    part of the batch statistics, as in the reference (the pad sits in front of the norm)."""
+
+    @staticmethod
+    def forward(ctx, x, wt, bt, gamma, beta, skip, pad, norm):
+        sd = x.dtype
+        x = N.to_ndhwc(x)
+        cin, cout = wt.shape[0], wt.shape[1]
+        cin_seg = seg_of(cin, x.shape[1]) if pad else 0
+        cout_seg = cout if pad else 0
+        if not pad and x.shape[1] != cin:
+            raise N.Ru3dError("ConvTrans3D: input has %d channels, weight expects %d" % (x.shape[1], cin))
+        cout_p = padded_dim(cout, cout_seg)
+        specs = [(wt, N.ROLE_CONVT_FWD, 2, cout_seg, cin_seg)]
+        if ctx.needs_input_grad[0]:
+            specs.append((wt, N.ROLE_CONVT_DGRAD, 2, cout_seg, cin_seg))
+        if cout_seg and bt is not None:
+            specs.append((bt, N.ROLE_BIAS, 1, cout_seg, 0))
+        packs = pack_weights(specs, sd)
+        btp = _f32_view(packs[-1], cout_p) if (cout_seg and bt is not None) else bt
+        y = convt_fwd(x, packs[0], btp, cout_p)
+        fs, fh, a_s, b_s, cnt = bn_train_stats(y, None, norm, cout)
+        n, _, d, h, w = y.shape
+        if skip is not None:
+            skip = as_grad(skip, sd)
+            cs = skip.shape[1]
+            if tuple(skip.shape[2:]) != (d, h, w) or skip.shape[0] != n:
+                raise N.Ru3dError("UpConcat: skip %s does not match up-sampled %s" % (tuple(skip.shape), tuple(y.shape)))
+            out = N.new_act(n, cout_p + cs, d, h, w, sd, x.device)
+            affine_lrelu_fwd(y, fs, fh, out=out[:, :cout_p])
+            copy_channels(skip, out[:, cout_p:])
+        else:
+            out = affine_lrelu_fwd(y, fs, fh)
+        ctx.save_for_backward(x, y, out, fs, a_s, b_s, packs[1] if ctx.needs_input_grad[0] else None)
+        ctx.dims = (cout, cin, cout_seg, cin_seg)
+        ctx.count = cnt
+        ctx.has_skip = skip is not None
+        ctx.has_b = bt is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, out, fs, a_s, b_s, pwd = ctx.saved_tensors
+        cout, cin, cout_seg, cin_seg = ctx.dims
+        cout_p = padded_dim(cout, cout_seg)
+        g = as_grad(g, x.dtype)
+        u = out[:, :cout_p] if ctx.has_skip else out
+        gu = g[:, :cout_p] if ctx.has_skip else g
+        gskip = g[:, cout_p:] if ctx.has_skip else None
+        dy, _, dgam, dbet = bn_lrelu_bwd(gu, u, y, a_s, b_s, fs, ctx.count, zero_far=True)
+        gw = unpad_wgrad(convt_wgrad(x, dy), cin, cout, cin_seg, cout_seg)
+        gb = channel_sum(dy)[:cout] if ctx.has_b else None
+        gx = convt_dgrad(dy, pwd, tuple(x.shape)) if ctx.needs_input_grad[0] else None
+        return (gx, gw, gb, dgam[:cout] if ctx.needs_input_grad[3] else None,
+                dbet[:cout] if ctx.needs_input_grad[4] else None, gskip, None, None)
 
 
 # --------------------------------------------------------------------------- autograd: attention gate (+ concat)

@@ -42,7 +42,11 @@
     X(ru3d_cast_f32) \
     X(ru3d_ncdhw_to_ndhwc) \
     X(ru3d_ndhwc_to_ncdhw) \
-    X(ru3d_pointwise)
+    X(ru3d_pointwise) \
+    X(ru3d_batchnorm_stats_pool) \
+    X(ru3d_affine_lrelu_fwd) \
+    X(ru3d_batchnorm_bwd_pool) \
+    X(ru3d_batchnorm_bwd_apply)
 
 #ifdef RU3D_STORAGE_F16
 #define ru3d_packed_weight_bytes ru3d_packed_weight_bytes_f16
@@ -85,4 +89,8 @@
 #define ru3d_ncdhw_to_ndhwc ru3d_ncdhw_to_ndhwc_f16
 #define ru3d_ndhwc_to_ncdhw ru3d_ndhwc_to_ncdhw_f16
 #define ru3d_pointwise ru3d_pointwise_f16
+#define ru3d_batchnorm_stats_pool ru3d_batchnorm_stats_pool_f16
+#define ru3d_affine_lrelu_fwd ru3d_affine_lrelu_fwd_f16
+#define ru3d_batchnorm_bwd_pool ru3d_batchnorm_bwd_pool_f16
+#define ru3d_batchnorm_bwd_apply ru3d_batchnorm_bwd_apply_f16
 #endif

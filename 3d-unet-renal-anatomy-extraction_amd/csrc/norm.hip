@@ -70,7 +70,9 @@ __global__ __launch_bounds__(256) void reduce2_kernel(const T* __restrict__ a, i
                                                       int ldb, const T* __restrict__ c3, int ldc,
                                                       const float* __restrict__ mean, const float* __restrict__ scale,
                                                       float slope, double* __restrict__ part, ChanLoop cl, int C,
-                                                      T* __restrict__ gp_out = nullptr, int ldgp = 0) {
+                                                      T* __restrict__ gp_out = nullptr, int ldgp = 0,
+                                                      const float* __restrict__ shift = nullptr) {
+    // MODE 5 = MODE 4 for BatchNorm: xhat = y * scale + shift with per-(n, c) values (mean unused)
     // MODE 4 = MODE 1 that also stores g' = gout * lrelu'(out) (the pre-activation gradient): the apply pass then reads
     // (g', y) instead of (gout, out, y) - one tensor pass fewer per residual block backward
     __shared__ double sh[2][256][VEC > 4 ? 4 : VEC];  // reduced in two halves when VEC == 8
@@ -84,10 +86,10 @@ __global__ __launch_bounds__(256) void reduce2_kernel(const T* __restrict__ a, i
     for (int i = 0; i < VEC; i++) s1[i] = s2[i] = 0.f;
     if (active) {
         float mu[VEC], sc[VEC];
-        if (MODE == 1 || MODE == 4) {
+        if (MODE == 1 || MODE == 4 || MODE == 5) {
 #pragma unroll
             for (int i = 0; i < VEC; i++) {
-                mu[i] = mean[n * C + cg * VEC + i];
+                mu[i] = MODE == 5 ? shift[n * C + cg * VEC + i] : mean[n * C + cg * VEC + i];
                 sc[i] = scale[n * C + cg * VEC + i];
             }
         }
@@ -104,20 +106,20 @@ __global__ __launch_bounds__(256) void reduce2_kernel(const T* __restrict__ a, i
                     s1[i] += av[i];
                     s2[i] = fmaf(av[i], av[i], s2[i]);
                 }
-            } else if (MODE == 1 || MODE == 4) {
+            } else if (MODE == 1 || MODE == 4 || MODE == 5) {
                 float ov[VEC], yv[VEC], pv[VEC];
                 load_vec<T, VEC>(b + row * ldb + cg * VEC, ov);
                 load_vec<T, VEC>(c3 + row * ldc + cg * VEC, yv);
 #pragma unroll
                 for (int i = 0; i < VEC; i++) {
                     float gp = ov[i] > 0.f ? av[i] : av[i] * slope;
-                    if (MODE == 4) gp = to_f32<T>(from_f32<T>(gp));      // the sums see the value the apply pass will read
+                    if (MODE >= 4) gp = to_f32<T>(from_f32<T>(gp));      // the sums see the value the apply pass will read
                     pv[i] = gp;
-                    const float xh = (yv[i] - mu[i]) * sc[i];
+                    const float xh = MODE == 5 ? fmaf(yv[i], sc[i], mu[i]) : (yv[i] - mu[i]) * sc[i];
                     s1[i] += gp;
                     s2[i] = fmaf(gp, xh, s2[i]);
                 }
-                if (MODE == 4) store_vec<T, VEC>(gp_out + row * ldgp + cg * VEC, pv);
+                if (MODE >= 4) store_vec<T, VEC>(gp_out + row * ldgp + cg * VEC, pv);
             } else if (MODE == 3) {
                 float ov[VEC];
                 load_vec<T, VEC>(b + row * ldb + cg * VEC, ov);
@@ -267,12 +269,14 @@ __global__ __launch_bounds__(256) void chansum_finalize_kernel(const double* __r
 
 // --------------------------------------------------------------------------- apply kernels
 // out = lrelu((y - mean) * scale (+ res))
-template <typename T, int VEC, bool HAS_RES>
+// AFFINE (BatchNorm): out = lrelu(y * scale + shift (+ res)) with per-(n, c) scale / shift; `mean` unused
+template <typename T, int VEC, bool HAS_RES, bool AFFINE = false>
 __global__ __launch_bounds__(256) void in_lrelu_fwd_kernel(const T* __restrict__ y, int ldy,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ scale, const T* __restrict__ res,
                                                            int ldr, T* __restrict__ out, int ldo, float slope,
-                                                           ChanLoop cl, int C) {
+                                                           ChanLoop cl, int C,
+                                                           const float* __restrict__ shift = nullptr) {
     const int tid = threadIdx.x;
     const int cgl = tid % cl.Gb, vl = tid / cl.Gb;
     const int cg = blockIdx.z * cl.Gb + cgl;
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(256) void in_lrelu_fwd_kernel(const T* __restrict__
     float mu[VEC], sc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; i++) {
-        mu[i] = mean[n * C + cg * VEC + i];
+        mu[i] = AFFINE ? shift[n * C + cg * VEC + i] : mean[n * C + cg * VEC + i];
         sc[i] = scale[n * C + cg * VEC + i];
     }
     const int v0 = blockIdx.x * cl.span;
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(256) void in_lrelu_fwd_kernel(const T* __restrict__
         if (HAS_RES) load_vec<T, VEC>(res + row * ldr + cg * VEC, rv);
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
-            float t = (yv[i] - mu[i]) * sc[i];
+            float t = AFFINE ? fmaf(yv[i], sc[i], mu[i]) : (yv[i] - mu[i]) * sc[i];
             if (HAS_RES) t += rv[i];
             ov[i] = lrelu_f(t, slope);
         }
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(256) void in_lrelu_fwd_kernel(const T* __restrict__
 
 // dy = scale * (gpre - m1 - xhat * m2), gpre = gout * lrelu'(out); optional gpre output; far planes zeroed
 // FROM_GPRE: `gpre` is an INPUT (written by reduce2 MODE 4): dy from (gpre, y) alone
-template <typename T, int VEC, bool HAS_GPRE, bool FROM_GPRE = false>
+template <typename T, int VEC, bool HAS_GPRE, bool FROM_GPRE = false, bool AFFINE = false>
 __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(const T* __restrict__ gout, int ldg,
                                                            const T* __restrict__ out, int ldo,
                                                            const T* __restrict__ y, int ldy,
@@ -312,20 +316,24 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(const T* __restrict__
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ m12, T* __restrict__ dy, int lddy,
                                                            T* __restrict__ gpre, int ldgp, float slope, int zero_far,
-                                                           int D, int H, int W, ChanLoop cl, int C) {
+                                                           int D, int H, int W, ChanLoop cl, int C,
+                                                           const float* __restrict__ shift = nullptr,
+                                                           const float* __restrict__ oscale = nullptr) {
+    // AFFINE (BatchNorm): xhat = y * scale + shift, dy = oscale * (...) with per-(n, c) values; `mean` unused
     const int tid = threadIdx.x;
     const int cgl = tid % cl.Gb, vl = tid / cl.Gb;
     const int cg = blockIdx.z * cl.Gb + cgl;
     const int n = blockIdx.y;
     if (vl >= cl.vpb || cg >= cl.G) return;
-    float mu[VEC], sc[VEC], m1[VEC], m2[VEC];
+    float mu[VEC], sc[VEC], m1[VEC], m2[VEC], osc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; i++) {
         const int idx = n * C + cg * VEC + i;
-        mu[i] = mean[idx];
+        mu[i] = AFFINE ? shift[idx] : mean[idx];
         sc[i] = scale[idx];
         m1[i] = m12[2 * idx];
         m2[i] = m12[2 * idx + 1];
+        osc[i] = AFFINE ? oscale[idx] : sc[i];
     }
     const float inv_slope = 1.f / slope;   // one division per thread, not eight per voxel
     const bool pow2 = (W & (W - 1)) == 0 && (H & (H - 1)) == 0;
@@ -355,9 +363,10 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(const T* __restrict__
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
             const float gp = FROM_GPRE ? gv[i] : (ov[i] > 0.f ? gv[i] : gv[i] * slope);
-            const float xh = HAS_GPRE ? (yv[i] - mu[i]) * sc[i] : (ov[i] > 0.f ? ov[i] : ov[i] * inv_slope);
+            const float xh = AFFINE ? fmaf(yv[i], sc[i], mu[i])
+                                    : (HAS_GPRE ? (yv[i] - mu[i]) * sc[i] : (ov[i] > 0.f ? ov[i] : ov[i] * inv_slope));
             pv[i] = gp;
-            dv[i] = far ? 0.f : sc[i] * (gp - m1[i] - xh * m2[i]);
+            dv[i] = far ? 0.f : osc[i] * (gp - m1[i] - xh * m2[i]);
         }
         store_vec<T, VEC>(dy + row * lddy + cg * VEC, dv);
         if (HAS_GPRE && !FROM_GPRE) store_vec<T, VEC>(gpre + row * ldgp + cg * VEC, pv);
@@ -618,6 +627,237 @@ extern "C" int ru3d_in_lrelu_bwd_apply(const ru3d_tensor* gout, const ru3d_tenso
     if (dtype == RU3D_F32) return in_bwd_apply_impl<float>(gout, out, mean, scale, m12, dy, slope, zero_far, as_stream(stream));
     if (dtype == RU3D_BF16) return in_bwd_apply_impl<bf16>(gout, out, mean, scale, m12, dy, slope, zero_far, as_stream(stream));
     return ru3d_fail(-1, "in_lrelu_bwd_apply: bad dtype %d", dtype);
+}
+
+// --------------------------------------------------------------------------- BatchNorm3d, training mode
+// Blocks built with norm_op=nn.BatchNorm3d (reference network.py:38-69, ResAttrBNUnet3D): statistics pooled over the
+// batch.  With u = d[n][c] * y (Dropout3d's per-(n, c) factor d in front of the norm, network.py:411-413):
+//     mu_c = sum_n d S1[n][c] / count,  var_c = sum_n d^2 S2[n][c] / count - mu_c^2,  r_c = 1 / sqrt(var_c + eps)
+//     xhat = y * a[n][c] + b[n][c]          a = d r_c, b = -mu_c r_c
+//     out  = lrelu(y * fscale + fshift (+ res))   fscale = gamma_c a, fshift = beta_c + gamma_c b
+//     dy   = fscale * (gpre - M1_c - xhat * M2_c),  M1 = sum gpre / count, M2 = sum gpre xhat / count,
+//     dgamma_c = sum gpre xhat, dbeta_c = sum gpre  (both over n and voxels).
+// The pooled sums are handed back to the caller as doubles between the two halves of each direction, so that a
+// multi-GPU caller can all-reduce them (SyncBN) - count is then the global element count.
+__global__ __launch_bounds__(256) void bn_pool_kernel(const double* __restrict__ part, int chunks, int C, int N,
+                                                      const float* __restrict__ drop, double* __restrict__ pooled) {
+    const int c = blockIdx.x * FIN_CX + threadIdx.x % FIN_CX;
+    const bool ok = c < C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int n = 0; n < N; n++) {
+        double t1, t2;
+        finalize_sums(part + (int64_t)n * chunks * C * 2, chunks, (int64_t)C * 2, ok ? c : 0, ok, t1, t2);
+        if (ok && threadIdx.x < FIN_CX) {
+            const double d = drop ? (double)drop[n * C + c] : 1.0;
+            s1 += d * t1;
+            s2 += d * d * t2;
+        }
+        __syncthreads();
+    }
+    if (ok && threadIdx.x < FIN_CX) {
+        pooled[2 * c] = s1;
+        pooled[2 * c + 1] = s2;
+    }
+}
+
+__global__ void bn_m12_kernel(const double* __restrict__ pooled, int N, int C, double inv_count,
+                              float* __restrict__ m12) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int c = i % C;
+    m12[2 * i] = (float)(pooled[2 * c] * inv_count);
+    m12[2 * i + 1] = (float)(pooled[2 * c + 1] * inv_count);
+}
+
+#ifndef RU3D_STORAGE_F16
+__global__ void bn_finalize_kernel(const double* __restrict__ pooled, int N, int C, int c_real, double inv_count,
+                                   double unbias, const float* __restrict__ drop, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ fscale, float* __restrict__ fshift, float* __restrict__ a,
+                                   float* __restrict__ b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i % C;
+    const double m = pooled[2 * c] * inv_count;
+    double var = pooled[2 * c + 1] * inv_count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double r = 1.0 / sqrt(var + (double)eps);
+    const double d = drop ? (double)drop[i] : 1.0;
+    const bool real = c < c_real;                    // channel padding: gamma = 1, beta = 0, no running statistics
+    const double g = (real && gamma) ? (double)gamma[c] : 1.0;
+    const double be = (real && beta) ? (double)beta[c] : 0.0;
+    a[i] = (float)(d * r);
+    b[i] = (float)(-m * r);
+    fscale[i] = (float)(g * d * r);
+    fshift[i] = (float)(be - g * m * r);
+    if (n == 0 && real && running_mean && running_var) {
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * var * unbias);
+    }
+}
+
+extern "C" int ru3d_batchnorm_stats_finalize(const double* pooled, int n, int c, int c_real, double count,
+                                             const float* drop_scale, const float* gamma, const float* beta, float eps,
+                                             float momentum, float* running_mean, float* running_var, float* fscale,
+                                             float* fshift, float* a, float* b, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(pooled && fscale && fshift && a && b, "batchnorm_stats_finalize: null pointer");
+    RU3D_REQUIRE(n > 0 && c > 0 && c_real > 0 && c_real <= c && count > 0.0, "batchnorm_stats_finalize: bad sizes");
+    RU3D_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "batchnorm_stats_finalize: half a running pair");
+    const double unbias = count > 1.0 ? count / (count - 1.0) : 1.0;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((n * c + 255) / 256), dim3(256), 0, as_stream(stream), pooled, n, c, c_real,
+                       1.0 / count, unbias, drop_scale, gamma, beta, eps, momentum, running_mean, running_var, fscale,
+                       fshift, a, b);
+    return ru3d_check_launch("batchnorm_stats_finalize");
+}
+#endif
+
+template <typename T>
+static int bn_pool_impl(const ru3d_tensor* y, const float* drop, double* pooled, void* ws, hipStream_t st) {
+    const int64_t V = (int64_t)y->d * y->h * y->w;
+    const int vec = pick_vec<T>(y->c, {y});
+    ChanLoop cl = make_chanloop(V, y->c, vec, 64, y->n);
+    dim3 grid(cl.chunks, y->n, (cl.G + cl.Gb - 1) / cl.Gb);
+    double* part = (double*)ws;
+#define CALL(TT, VV)                                                                                              \
+    hipLaunchKernelGGL((reduce2_kernel<TT, VV, 0>), grid, dim3(256), 0, st, (const TT*)y->ptr, y->ld, (const TT*)0, \
+                       0, (const TT*)0, 0, (const float*)0, (const float*)0, 0.f, part, cl, y->c)
+    DISPATCH_VEC(T, vec, CALL)
+#undef CALL
+    int rc = ru3d_check_launch("batchnorm_stats_reduce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_pool_kernel, dim3((y->c + FIN_CX - 1) / FIN_CX), dim3(256), 0, st, (const double*)part, cl.chunks,
+                       y->c, y->n, drop, pooled);
+    return ru3d_check_launch("batchnorm_stats_pool");
+}
+
+extern "C" int ru3d_batchnorm_stats_pool(const ru3d_tensor* y, const float* drop_scale, double* pooled, void* ws,
+                                         size_t ws_bytes, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_batchnorm_stats_pool_f16(y, drop_scale, pooled, ws, ws_bytes, dtype, stream));
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(tensor_ok(y), "batchnorm_stats_pool: bad tensor");
+    RU3D_REQUIRE(pooled && ws, "batchnorm_stats_pool: null output/workspace");
+    RU3D_REQUIRE(ws_bytes >= reduce_ws_bytes(y), "batchnorm_stats_pool: workspace too small (%zu < %zu)", ws_bytes,
+                 reduce_ws_bytes(y));
+    RU3D_REQUIRE((int64_t)y->d * y->h * y->w < (1ll << 31), "batchnorm_stats_pool: sample too large");
+    if (dtype == RU3D_F32) return bn_pool_impl<float>(y, drop_scale, pooled, ws, as_stream(stream));
+    if (dtype == RU3D_BF16) return bn_pool_impl<bf16>(y, drop_scale, pooled, ws, as_stream(stream));
+    return ru3d_fail(-1, "batchnorm_stats_pool: bad dtype %d", dtype);
+}
+
+// out = lrelu(y * scale[n][c] + shift[n][c] (+ res))
+template <typename T>
+static int affine_fwd_impl(const ru3d_tensor* y, const float* scale, const float* shift, const ru3d_tensor* res,
+                           const ru3d_tensor* out, float slope, hipStream_t st) {
+    const int64_t V = (int64_t)y->d * y->h * y->w;
+    const int vec = pick_vec<T>(y->c, {y, res, out});
+    ChanLoop cl = make_chanloop(V, y->c, vec, 16, y->n);
+    dim3 grid(cl.chunks, y->n, (cl.G + cl.Gb - 1) / cl.Gb);
+#define CALL(TT, VV)                                                                                               \
+    if (res)                                                                                                       \
+        hipLaunchKernelGGL((in_lrelu_fwd_kernel<TT, VV, true, true>), grid, dim3(256), 0, st, (const TT*)y->ptr,    \
+                           y->ld, (const float*)0, scale, (const TT*)res->ptr, res->ld, (TT*)out->ptr, out->ld,    \
+                           slope, cl, y->c, shift);                                                                \
+    else                                                                                                           \
+        hipLaunchKernelGGL((in_lrelu_fwd_kernel<TT, VV, false, true>), grid, dim3(256), 0, st, (const TT*)y->ptr,   \
+                           y->ld, (const float*)0, scale, (const TT*)0, 0, (TT*)out->ptr, out->ld, slope, cl, y->c, \
+                           shift)
+    DISPATCH_VEC(T, vec, CALL)
+#undef CALL
+    return ru3d_check_launch("affine_lrelu_fwd");
+}
+
+extern "C" int ru3d_affine_lrelu_fwd(const ru3d_tensor* y, const float* scale, const float* shift, const ru3d_tensor* res,
+                                     const ru3d_tensor* out, float slope, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_affine_lrelu_fwd_f16(y, scale, shift, res, out, slope, dtype, stream));
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(tensor_ok(y) && tensor_ok(out) && same_shape(y, out), "affine_lrelu_fwd: bad y/out");
+    RU3D_REQUIRE(!res || (tensor_ok(res) && same_shape(y, res)), "affine_lrelu_fwd: bad residual");
+    RU3D_REQUIRE(scale && shift, "affine_lrelu_fwd: null scale/shift");
+    RU3D_REQUIRE((int64_t)y->d * y->h * y->w < (1ll << 31), "affine_lrelu_fwd: sample too large");
+    if (dtype == RU3D_F32) return affine_fwd_impl<float>(y, scale, shift, res, out, slope, as_stream(stream));
+    if (dtype == RU3D_BF16) return affine_fwd_impl<bf16>(y, scale, shift, res, out, slope, as_stream(stream));
+    return ru3d_fail(-1, "affine_lrelu_fwd: bad dtype %d", dtype);
+}
+
+// backward, first half: gpre = gout * lrelu'(out) stored, pooled = (sum gpre, sum gpre * xhat) over n and voxels
+template <typename T>
+static int bn_bwd_pool_impl(const ru3d_tensor* gout, const ru3d_tensor* out, const ru3d_tensor* y, const float* a,
+                            const float* b, const ru3d_tensor* gpre, double* pooled, void* ws, float slope,
+                            hipStream_t st) {
+    const int64_t V = (int64_t)y->d * y->h * y->w;
+    const int vec = pick_vec<T>(y->c, {gout, out, y, gpre});
+    ChanLoop cl = make_chanloop(V, y->c, vec, 64, y->n);
+    dim3 grid(cl.chunks, y->n, (cl.G + cl.Gb - 1) / cl.Gb);
+    double* part = (double*)ws;
+#define CALL(TT, VV)                                                                                                  \
+    hipLaunchKernelGGL((reduce2_kernel<TT, VV, 5>), grid, dim3(256), 0, st, (const TT*)gout->ptr, gout->ld,           \
+                       (const TT*)out->ptr, out->ld, (const TT*)y->ptr, y->ld, (const float*)0, a, slope, part, cl,   \
+                       y->c, (TT*)gpre->ptr, gpre->ld, b)
+    DISPATCH_VEC(T, vec, CALL)
+#undef CALL
+    int rc = ru3d_check_launch("batchnorm_bwd_reduce");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_pool_kernel, dim3((y->c + FIN_CX - 1) / FIN_CX), dim3(256), 0, st, (const double*)part, cl.chunks,
+                       y->c, y->n, (const float*)0, pooled);
+    return ru3d_check_launch("batchnorm_bwd_pool");
+}
+
+extern "C" int ru3d_batchnorm_bwd_pool(const ru3d_tensor* gout, const ru3d_tensor* out, const ru3d_tensor* y,
+                                       const float* a, const float* b, const ru3d_tensor* gpre, double* pooled, void* ws,
+                                       size_t ws_bytes, float slope, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_batchnorm_bwd_pool_f16(gout, out, y, a, b, gpre, pooled, ws, ws_bytes, slope, dtype, stream));
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(tensor_ok(gout) && tensor_ok(out) && tensor_ok(y) && tensor_ok(gpre), "batchnorm_bwd_pool: bad tensor");
+    RU3D_REQUIRE(same_shape(y, gout) && same_shape(y, out) && same_shape(y, gpre), "batchnorm_bwd_pool: shape mismatch");
+    RU3D_REQUIRE(a && b && pooled && ws, "batchnorm_bwd_pool: null pointer");
+    RU3D_REQUIRE(ws_bytes >= reduce_ws_bytes(y), "batchnorm_bwd_pool: workspace too small (%zu < %zu)", ws_bytes,
+                 reduce_ws_bytes(y));
+    RU3D_REQUIRE((int64_t)y->d * y->h * y->w < (1ll << 31), "batchnorm_bwd_pool: sample too large");
+    if (dtype == RU3D_F32) return bn_bwd_pool_impl<float>(gout, out, y, a, b, gpre, pooled, ws, slope, as_stream(stream));
+    if (dtype == RU3D_BF16) return bn_bwd_pool_impl<bf16>(gout, out, y, a, b, gpre, pooled, ws, slope, as_stream(stream));
+    return ru3d_fail(-1, "batchnorm_bwd_pool: bad dtype %d", dtype);
+}
+
+// backward, second half: dy = fscale * (gpre - M1 - xhat * M2) with M = pooled / count
+static void bn_m12_launch(const double* pooled, int n, int c, double count, float* m12, hipStream_t st) {
+    hipLaunchKernelGGL(bn_m12_kernel, dim3((n * c + 255) / 256), dim3(256), 0, st, pooled, n, c, 1.0 / count, m12);
+}
+
+template <typename T>
+static int bn_bwd_apply_impl(const ru3d_tensor* gpre, const ru3d_tensor* y, const float* a, const float* b,
+                             const float* fscale, const float* m12, const ru3d_tensor* dy, int zero_far, hipStream_t st) {
+    const int64_t V = (int64_t)y->d * y->h * y->w;
+    const int vec = pick_vec<T>(y->c, {gpre, y, dy});
+    ChanLoop ca = make_chanloop(V, y->c, vec, 16, y->n);
+    dim3 grida(ca.chunks, y->n, (ca.G + ca.Gb - 1) / ca.Gb);
+#define CALL(TT, VV)                                                                                                  \
+    hipLaunchKernelGGL((in_lrelu_bwd_kernel<TT, VV, true, true, true>), grida, dim3(256), 0, st, (const TT*)0, 0,      \
+                       (const TT*)0, 0, (const TT*)y->ptr, y->ld, (const float*)0, a, m12, (TT*)dy->ptr, dy->ld,      \
+                       (TT*)gpre->ptr, gpre->ld, 0.f, zero_far, y->d, y->h, y->w, ca, y->c, b, fscale)
+    DISPATCH_VEC(T, vec, CALL)
+#undef CALL
+    return ru3d_check_launch("batchnorm_bwd_apply");
+}
+
+extern "C" int ru3d_batchnorm_bwd_apply(const ru3d_tensor* gpre, const ru3d_tensor* y, const float* a, const float* b,
+                                        const float* fscale, const double* pooled, double count, const ru3d_tensor* dy,
+                                        void* ws, size_t ws_bytes, int zero_far, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_batchnorm_bwd_apply_f16(gpre, y, a, b, fscale, pooled, count, dy, ws, ws_bytes, zero_far, dtype, stream));
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(tensor_ok(gpre) && tensor_ok(y) && tensor_ok(dy), "batchnorm_bwd_apply: bad tensor");
+    RU3D_REQUIRE(same_shape(y, gpre) && same_shape(y, dy), "batchnorm_bwd_apply: shape mismatch");
+    RU3D_REQUIRE(a && b && fscale && pooled && ws && count > 0.0, "batchnorm_bwd_apply: null pointer / bad count");
+    RU3D_REQUIRE(ws_bytes >= (size_t)y->n * y->c * 2 * sizeof(float), "batchnorm_bwd_apply: workspace too small");
+    RU3D_REQUIRE((int64_t)y->d * y->h * y->w < (1ll << 31), "batchnorm_bwd_apply: sample too large");
+    float* m12 = (float*)ws;
+    bn_m12_launch(pooled, y->n, y->c, count, m12, as_stream(stream));
+    int rc = ru3d_check_launch("batchnorm_bwd_means");
+    if (rc) return rc;
+    if (dtype == RU3D_F32) return bn_bwd_apply_impl<float>(gpre, y, a, b, fscale, m12, dy, zero_far, as_stream(stream));
+    if (dtype == RU3D_BF16) return bn_bwd_apply_impl<bf16>(gpre, y, a, b, fscale, m12, dy, zero_far, as_stream(stream));
+    return ru3d_fail(-1, "batchnorm_bwd_apply: bad dtype %d", dtype);
 }
 
 template <typename T>

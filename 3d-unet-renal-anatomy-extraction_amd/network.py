@@ -117,6 +117,17 @@ def _inference_mode(module):
     return (not module.training) and (not torch.is_grad_enabled())
 
 
+def _bn_on_device(module):
+    """A BatchNorm block runs on the native kernels: in inference mode (running statistics) and in training mode."""
+    return _inference_mode(module) or (module.training and _bn_native_train())
+
+
+def _bn_native_train():
+    """BatchNorm blocks train on the native kernels (ops.ResBlockBNFn / UpBNFn); RU3D_BN_TRAIN=torch keeps them torch
+    modules in training mode (the round-2 behaviour, kept as a cross-check)."""
+    return os.environ.get("RU3D_BN_TRAIN", "native") != "torch"
+
+
 def _is_plain_lrelu(act):
     return type(act) is nn.LeakyReLU and abs(act.negative_slope - ops.LRELU_SLOPE) < 1e-12
 
@@ -263,6 +274,9 @@ class ConvTrans3D(nn.Module):
         if self._bn_eval and x.is_cuda and _inference_mode(self):
             u = self._forward_bn_eval(x)
             return u if skip is None else ops.concat_channels(u, skip)
+        if self._bn_eval and x.is_cuda and self.training and _bn_native_train():
+            bn = self.up[2]
+            return ops.UpBNFn.apply(x, self.up[0].weight, self.up[0].bias, bn.weight, bn.bias, skip, self._pad, bn)
         y = self.up(x)
         return y if skip is None else torch.cat((y, skip), dim=1)
 
@@ -302,7 +316,7 @@ class UpConcat(nn.Module):
         if not self.attention and isinstance(self.conv_trans, ConvTrans3D):
             return self.conv_trans(x, skip, link)    # up-sampled channels first, skip second
         if (self.attention and isinstance(self.conv_trans, ConvTrans3D) and self.att_gate._native and x.is_cuda
-                and (self.conv_trans._native or (self.conv_trans._bn_eval and _inference_mode(self)))):
+                and (self.conv_trans._native or (self.conv_trans._bn_eval and _bn_on_device(self)))):
             up = self.conv_trans(x)
             return ops.AttGateFn.apply(skip, up, self.att_gate.conv.weight, self.att_gate.conv.bias,
                                        self.conv_trans._pad)
@@ -383,6 +397,13 @@ class ResBlock(nn.Module):
             N.require_device(x, "ResBlock input")
         if self._bn_eval and x.is_cuda and _inference_mode(self):
             return self._forward_bn_eval(x)
+        if (self._bn_eval and x.is_cuda and self.training and _bn_native_train()
+                and (self.dropout is None or type(self.dropout) is nn.Dropout3d)):
+            skip_w = self.skip_conv.weight if self.uses_skip_conv else None
+            skip_b = self.skip_conv.bias if self.uses_skip_conv else None
+            return ops.ResBlockBNFn.apply(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
+                                          skip_w, skip_b, self.norm.weight, self.norm.bias, self.stride,
+                                          self._drop_scale(x), self._in_segs if self._pad else 0, self.norm)
         skip = self.skip_conv(x) if self.uses_skip_conv else x
         x = self.conv1(x)
         if self.dropout:
@@ -557,7 +578,7 @@ class Unet(nn.Module):
     def _storage_dtype(self):
         """16-bit storage only where the blocks behind the stem consume it: an all-native InstanceNorm chain, or a
         BatchNorm chain in inference mode; torch-module blocks (BatchNorm training, custom blocks) get fp32."""
-        if self._in_chain or (self._bn_blocks is not None and _inference_mode(self)):
+        if self._in_chain or (self._bn_blocks is not None and _bn_on_device(self)):
             return self.compute_dtype
         return torch.float32
 
@@ -583,7 +604,7 @@ class Unet(nn.Module):
 
     def forward(self, x):
         if self._bn_blocks is not None:
-            self._set_bn_pad(self._pad_bn and x.is_cuda and _inference_mode(self))
+            self._set_bn_pad(self._pad_bn and x.is_cuda and _bn_on_device(self))
         x = self._stem(x)
         skips, links = [], []
         linked = self._linked and x.is_cuda
@@ -680,9 +701,10 @@ class ResAttrUnet3D2(_UnetWrapper):
 
 
 class ResAttrBNUnet3D(_UnetWrapper):
-    """BatchNorm + attention variant.  Training runs its blocks as torch modules (batch statistics, running averages);
-    inference (eval + no_grad - how the reference's scripts use this net, as the coarse model of nb_post_iia.py:20)
-    runs on the native kernels: BatchNorm with running statistics is a per-channel affine map."""
+    """BatchNorm + attention variant, on the native kernels in both modes.  Training: batch-pooled statistics with the
+    Dropout3d factors folded in, running averages, gamma / beta gradients (ops.ResBlockBNFn / UpBNFn; RU3D_BN_TRAIN=torch
+    keeps the blocks torch modules as a cross-check).  Inference (eval + no_grad - how the reference's scripts use this
+    net, as the coarse model of nb_post_iia.py:20): BatchNorm with running statistics is a per-channel affine map."""
 
     def __init__(self, num_pool=4, num_features=30, in_channels=1, out_channels=1):
         super().__init__()

@@ -285,6 +285,12 @@ class Trainer():
             # all ranks end up on one transport (RCCL when every rank can load it, torch.distributed otherwise)
             on_gpu = self.device.type == 'cuda' and dist.get_backend() != "gloo"
             self._grad_sync = make_grad_sync(self.model, transport=os.environ.get("RU3D_COMM", "rccl" if on_gpu else "torch"))
+            # BatchNorm nets: each rank normalises its own sub-batch, as the reference's nn.DataParallel replicas do
+            # (trainer.py:531-535; rank 0's running averages are the ones checkpointed); RU3D_SYNC_BN=1 pools the
+            # statistics over the ranks instead (SyncBN, ops.set_bn_sync)
+            if os.environ.get("RU3D_SYNC_BN", "0") == "1":
+                import _ops as ops
+                ops.set_bn_sync()
         box = [self.train_indices, self.valid_indices, self.current_epoch]
         dist.broadcast_object_list(box, src=0)
         self.train_indices, self.valid_indices, self.current_epoch = box

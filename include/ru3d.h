@@ -344,6 +344,36 @@ int ru3d_conv3d_dgrad_in_bwd(const ru3d_tensor* dy, const void* w_packed, const 
 int ru3d_in_lrelu_bwd_apply(const ru3d_tensor* gout, const ru3d_tensor* out, const float* mean, const float* scale,
                             const float* m12, const ru3d_tensor* dy, float slope, int zero_far, int dtype, void* stream);
 
+/* ------------------------------------------------------------------ BatchNorm3d, training mode - */
+/* Blocks built with norm_op=nn.BatchNorm3d (network.py:38-69 ResAttrBNUnet3D; nn.BatchNorm3d(C) defaults: affine,
+ * running statistics, momentum 0.1, eps 1e-5) in training mode: statistics pooled over the batch, with the preceding
+ * nn.Dropout3d's per-(n, c) factor d folded in (network.py:411-413).  Each direction is two calls with the pooled sums
+ * handed back in between as doubles, so that a multi-GPU caller can all-reduce them (SyncBN; count is then the global
+ * element count N * D * H * W summed over ranks).
+ *   stats_pool:     pooled[2c] = sum_n d sum_v y, pooled[2c+1] = sum_n d^2 sum_v y^2     (ws: ru3d_reduce_workspace_bytes)
+ *   stats_finalize: mu = pooled[2c] / count, var = pooled[2c+1] / count - mu^2 (biased), r = 1 / sqrt(var + eps);
+ *                   a[n][c] = d r, b[n][c] = -mu r (x_hat = y a + b), fscale = gamma a, fshift = beta + gamma b;
+ *                   running_mean / running_var (NULL: not tracked) move by `momentum` towards mu / the unbiased var.
+ *                   c_real <= c: channels beyond it are zero padding (gamma = 1, beta = 0, no running update).
+ *   affine_lrelu_fwd: out = LeakyReLU(y * scale[n][c] + shift[n][c] (+ res), slope)
+ *   bwd_pool:       gpre = gout * LeakyReLU'(out) is stored; pooled[2c] = sum gpre (= dbeta of this rank),
+ *                   pooled[2c+1] = sum gpre x_hat (= dgamma of this rank)
+ *   bwd_apply:      dy = fscale * (gpre - pooled[2c] / count - x_hat * pooled[2c+1] / count); zero_far as in
+ *                   ru3d_in_lrelu_bwd; ws: 2 * N * C floats. */
+int ru3d_batchnorm_stats_pool(const ru3d_tensor* y, const float* drop_scale, double* pooled, void* ws, size_t ws_bytes,
+                              int dtype, void* stream);
+int ru3d_batchnorm_stats_finalize(const double* pooled, int n, int c, int c_real, double count, const float* drop_scale,
+                                  const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                  float* running_var, float* fscale, float* fshift, float* a, float* b, void* stream);
+int ru3d_affine_lrelu_fwd(const ru3d_tensor* y, const float* scale, const float* shift, const ru3d_tensor* res,
+                          const ru3d_tensor* out, float slope, int dtype, void* stream);
+int ru3d_batchnorm_bwd_pool(const ru3d_tensor* gout, const ru3d_tensor* out, const ru3d_tensor* y, const float* a,
+                            const float* b, const ru3d_tensor* gpre, double* pooled, void* ws, size_t ws_bytes,
+                            float slope, int dtype, void* stream);
+int ru3d_batchnorm_bwd_apply(const ru3d_tensor* gpre, const ru3d_tensor* y, const float* a, const float* b,
+                             const float* fscale, const double* pooled, double count, const ru3d_tensor* dy, void* ws,
+                             size_t ws_bytes, int zero_far, int dtype, void* stream);
+
 /* Dynamic loss scaling of the fp16 mode (the reference's apex O1: trainer.py:492-493 amp.scale_loss, 538-542
  * amp.initialize): every gradient named by the table (same layout as ru3d_adam_multi; only grad / count are read) is
  * checked for inf / nan - *found_inf is set to 1.0 when one is found; the caller zeroes it beforehand - and multiplied

@@ -6,6 +6,7 @@ modes
   hip_dp     the HIP config-1 model (fp32 parity mode) under data parallelism on ONE device over gloo (RCCL refuses
              two ranks on one GPU): rank-different initial weights -> broadcast, one averaged backward, three fused
              Adam steps on the bucket-aliased gradients, one Dropout3d mask draw.
+  sync_bn    a BatchNorm ResBlock with the pooled sums all-reduced over two ranks (SyncBN).
   rccl_w1    the RCCL wrapper of the C ABI with a world of one rank: communicator from a unique id, fp32 / bf16
              all-reduce on a side stream, GradSync(transport="rccl") around the HIP model.
 """
@@ -163,12 +164,38 @@ def rccl_w1(out):
     torch.save(res, os.path.join(out, "rccl_w1.pt"))
 
 
+def sync_bn(out):
+    """A BatchNorm ResBlock (fp32 storage) in training mode with ops.set_bn_sync(): every rank normalises with the
+    statistics of the WHOLE batch (both directions pool their sums across ranks)."""
+    import network
+    import _ops as ops
+    rank = dist.get_rank()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)                       # same block on every rank
+    blk = network.ResBlock(8, 16, stride=2, norm_op=torch.nn.BatchNorm3d, dropout_op=None).to(dev).train()
+    with torch.no_grad():
+        blk.norm.weight.uniform_(0.5, 1.5)
+        blk.norm.bias.uniform_(-0.3, 0.3)
+    g = torch.Generator().manual_seed(40 + rank)
+    x = torch.randn(2, 8, 12, 8, 8, generator=g).to(dev).requires_grad_(True)
+    gout = torch.randn(2, 16, 6, 4, 4, generator=g).to(dev)
+    ops.set_bn_sync()
+    z = blk(x)
+    z.backward(gout)
+    ops.set_bn_sync(enable=False)
+    torch.cuda.synchronize()
+    torch.save({"x": x.detach().cpu(), "gout": gout.cpu(), "z": z.detach().cpu(), "gx": x.grad.cpu(),
+                "state": {k: v.detach().cpu() for k, v in blk.state_dict().items()},
+                "grads": {k: p.grad.cpu() for k, p in blk.named_parameters() if p.grad is not None}},
+               os.path.join(out, "syncbn%d.pt" % rank))
+
+
 def main():
     mode, out = sys.argv[1], sys.argv[2]
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     try:
-        {"hip_dp": hip_dp, "rccl_w1": rccl_w1}[mode](out)
+        {"hip_dp": hip_dp, "rccl_w1": rccl_w1, "sync_bn": sync_bn}[mode](out)
     finally:
         dist.destroy_process_group()
 

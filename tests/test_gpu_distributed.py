@@ -101,6 +101,41 @@ def test_two_ranks_hip_model_mean_of_oracle_shard_gradients(tmp_path):
     assert set(res[0]["mask"].unique().tolist()) <= {0.0, 2.0}
 
 
+def test_sync_batchnorm_two_ranks_equals_one_big_batch(tmp_path):
+    """ops.set_bn_sync(): two ranks with two samples each == one process with the four samples (torch modules, fp64):
+    outputs, input gradients, running statistics; parameter gradients are per-rank sums that add up to the big batch's."""
+    import copy
+    import network
+    out = str(tmp_path)
+    _run_ranks("sync_bn", 2, out)
+    res = [torch.load(os.path.join(out, "syncbn%d.pt" % r), weights_only=False) for r in range(2)]
+    torch.manual_seed(11)
+    blk = network.ResBlock(8, 16, stride=2, norm_op=torch.nn.BatchNorm3d, dropout_op=None)
+    init = {k: v for k, v in res[0]["state"].items() if "running" not in k and "num_batches" not in k}
+    blk.load_state_dict(init, strict=False)      # the children drew gamma / beta after construction
+    blk = blk.double().train()
+    x = torch.cat([r["x"] for r in res]).double().requires_grad_(True)
+    gout = torch.cat([r["gout"] for r in res]).double()
+    z = blk(x)
+    z.backward(gout)
+    for r in range(2):
+        sl = slice(2 * r, 2 * r + 2)
+        assert (res[r]["z"].double() - z[sl].detach()).abs().max().item() <= 2e-4
+        assert (res[r]["gx"].double() - x.grad[sl]).abs().max().item() <= 2e-3 * max(1.0, x.grad.abs().max().item())
+        for k in ("norm.running_mean", "norm.running_var"):
+            assert (res[r]["state"][k].double() - blk.state_dict()[k]).abs().max().item() <= 1e-5, k
+    assert torch.equal(res[0]["state"]["norm.running_var"], res[1]["state"]["norm.running_var"])
+    for k, p in blk.named_parameters():
+        if p.grad is None:
+            continue
+        total = res[0]["grads"][k].double() + res[1]["grads"][k].double()
+        if k in ("conv1.bias", "conv2.bias"):     # in front of a batch norm without dropout: analytically zero
+            assert total.abs().max().item() <= 1e-3 and p.grad.abs().max().item() < 1e-9, k
+            continue
+        scale = max(p.grad.abs().max().item(), 1e-3)
+        assert (total - p.grad).abs().max().item() <= 5e-3 * scale, k
+
+
 def test_rccl_wrapper_world_of_one(tmp_path):
     out = str(tmp_path)
     _run_ranks("rccl_w1", 1, out)

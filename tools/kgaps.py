@@ -1,37 +1,30 @@
-"""Idle time between kernels of a rocprofv3 --kernel-trace run: python tools/kgaps.py <dir> [steps]
-Sorts the dispatches by start time, prints wall span, union-busy time, and the idle gaps attributed to the kernel that
-FOLLOWS each gap (the one whose launch / dependency wait the gap is), so tiny dependent launches show their real cost:
-duration + the bubble in front of them."""
+"""Idle time between consecutive kernels of a rocprofv3 --kernel-trace run: python tools/kgaps.py <dir> [tail_fraction]
+Takes the last <tail_fraction> of the trace (the timed steps), sorts by start, reports busy / idle time and the gap
+histogram, and which kernels the largest gaps precede."""
 import csv, glob, re, sys
-d = sys.argv[1]; steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+d = sys.argv[1]; frac = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
 f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = []
 for r in csv.DictReader(open(f)):
     name = re.sub(r"\(anonymous namespace\)::|ru3d_bf16::|ru3d_f16::|void ", "", r["Kernel_Name"])
-    name = re.sub(r"\(.*$", "", name)
-    name = re.sub(r"<.*$", "", name)[:40]
-    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), re.sub(r"\(.*$", "", name)[:50]))
 rows.sort()
-# drop the first third (warm-up, allocator growth) - keep the dispatches of the last `steps` steps if the caller
-# profiled only timed steps; otherwise everything
-busy = 0; cur_end = rows[0][0]; gaps = {}; durs = {}; biggest = []
-for s, e, n in rows:
-    a = durs.setdefault(n, [0, 0.0]); a[0] += 1; a[1] += (e - s) / 1e3
-    if s > cur_end:
-        g = (s - cur_end) / 1e3
-        if g < 200:                      # host-side pauses between steps / syncs are not launch bubbles
-            ga = gaps.setdefault(n, [0, 0.0]); ga[0] += 1; ga[1] += g
-        else:
-            biggest.append((g, n))
-        busy += e - s; cur_end = e
-    else:
-        if e > cur_end:
-            busy += e - cur_end; cur_end = e
-span = (rows[-1][1] - rows[0][0]) / 1e6
-gap_tot = sum(v[1] for v in gaps.values()) / 1e3
-print("dispatches %d, span %.2f ms, union busy %.2f ms, bubbles < 200 us: %.2f ms (%.3f ms/step), long pauses: %d (%.2f ms)"
-      % (len(rows), span, busy / 1e6, gap_tot, gap_tot / steps, len(biggest), sum(g for g, _ in biggest) / 1e3))
-print("%-42s %8s %10s %10s %12s" % ("kernel (follows the bubble)", "calls/st", "dur us", "bubble us", "bubble ms/st"))
-for n, (c, g) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:40]:
-    dn = durs[n]
-    print("%-42s %8.1f %10.1f %10.2f %12.3f" % (n, dn[0] / steps, dn[1] / dn[0], g / c, g / 1e3 / steps))
+rows = rows[int(len(rows) * (1 - frac)):]
+busy = sum(e - s for s, e, _ in rows)
+span = rows[-1][1] - rows[0][0]
+gaps = []
+for (s0, e0, n0), (s1, e1, n1) in zip(rows, rows[1:]):
+    gaps.append((s1 - e0, n0, n1))
+idle = sum(max(g, 0) for g, _, _ in gaps)
+over = sum(-min(g, 0) for g, _, _ in gaps)
+print("kernels %d  span %.3f ms  busy %.3f ms  idle %.3f ms (%.1f%%)  overlap %.3f ms" % (len(rows), span / 1e6, busy / 1e6, idle / 1e6, 100.0 * idle / span, over / 1e6))
+edges = [0, 500, 1000, 2000, 3000, 5000, 10000, 50000, 10**9]
+for lo, hi in zip(edges, edges[1:]):
+    sel = [g for g, _, _ in gaps if lo <= g < hi]
+    print("  gap %6d..%-9d ns: %5d gaps, %.3f ms" % (lo, hi, len(sel), sum(sel) / 1e6))
+agg = {}
+for g, n0, n1 in gaps:
+    a = agg.setdefault((n0, n1), [0, 0]); a[0] += 1; a[1] += max(g, 0)
+print("largest idle by (previous -> next):")
+for (n0, n1), (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+    print("  %-50s -> %-50s n %4d  avg %7.2f us  total %.3f ms" % (n0, n1, c, t / c / 1e3, t / 1e6))
