@@ -168,9 +168,14 @@ def note_device(device):
     _tls.device = device
 
 
-def stream():
+def stream(device=None):
     """HIP stream handed to the C ABI: torch's current stream OF THE OPERANDS' DEVICE (not of whatever device the
-    calling thread has current).  The library makes that stream's device current for the launch."""
+    calling thread has current).  The library makes that stream's device current for the launch.  device: the
+    operands' device when the caller has it at hand; otherwise the one the last desc() / note_device() /
+    require_device() of this thread noted - ptr() checks every operand against it, so a stale note cannot send one
+    GPU's pointers to another GPU's stream."""
+    if device is not None:
+        _tls.device = device
     dev = getattr(_tls, "device", None)
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
@@ -260,7 +265,14 @@ def ref(d):
 
 
 def ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    if t is None:
+        return None
+    if t.is_cuda:
+        dev = getattr(_tls, "device", None)
+        if dev is not None and t.device != dev:
+            raise Ru3dError("ru3d: operand on %s in a call assembled for %s (operands of one entry point must share a "
+                            "device; note_device() / stream(device) name it)" % (t.device, dev))
+    return ctypes.c_void_p(t.data_ptr())
 
 
 # --------------------------------------------------------------------------- workspace

@@ -123,8 +123,22 @@ class GraphedTrainStep:
         return self.loss
 
     def release(self):
-        """Drop the graph and its memory pool; step counts go back into the optimizer state."""
+        """Drop the graph AND everything that keeps its private memory pool alive; step counts go back into the
+        optimizer state.  What points into the pool after a capture: the parameters' .grad tensors (the captured backward
+        allocated them), the workspace of the capture stream (_native._WS), the captured Adam launch plans, the static
+        input / output buffers - the pool returns to the allocator only when all of them are gone."""
         self.optimizer.sync_captured_steps()
         self.optimizer._captured = None
+        for key in [k for k in self.optimizer._plans if k[1]]:       # (group, captured=True)
+            del self.optimizer._plans[key]
+        if self.graph is not None:
+            self.optimizer.zero_grad(set_to_none=True)
+            sid = self.stream.cuda_stream
+            for key in [k for k in N._WS if k[1] == sid]:
+                del N._WS[key]
+            for name in ("x", "y", "loss", "logits", "_static_logits", "block", "drop_base", "hyper", "host", "host_ev",
+                         "stream"):
+                if hasattr(self, name):
+                    delattr(self, name)
         self.graph = None
         self.key = None

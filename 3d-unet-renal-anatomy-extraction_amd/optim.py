@@ -211,7 +211,7 @@ class _GradTable:
 class LossScaler:
     """Dynamic loss scaling for fp16 storage - the reference's apex O1 behaviour (trainer.py:492-493 `amp.scale_loss`,
     538-542 `amp.initialize(..., opt_level)`): start at 2**16, skip the optimizer step and halve the scale when a
-    gradient overflows, double it after `growth_interval` (2000) clean steps.
+    gradient overflows, double it after `growth_interval` (2000) clean steps, up to 2**24 (apex's max_loss_scale).
 
         scaler = optim.LossScaler()
         scaler.scale(loss).backward()
@@ -221,11 +221,12 @@ class LossScaler:
     gradients unscaled in place first.  bf16 storage needs none of this."""
 
     def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000,
-                 min_scale=2.0 ** -24):
+                 min_scale=2.0 ** -24, max_scale=2.0 ** 24):
         self.loss_scale = float(init_scale)
         self.growth_factor, self.backoff_factor = float(growth_factor), float(backoff_factor)
         self.growth_interval = int(growth_interval)
         self.min_scale = float(min_scale)
+        self.max_scale = float(max_scale)      # apex: max_loss_scale = 2.**24
         self.growth_tracker = 0
         self.skipped_steps = 0
         self._scale_t = None
@@ -268,19 +269,35 @@ class LossScaler:
                 optimizer.step()
             self.growth_tracker += 1
             if self.growth_tracker >= self.growth_interval:
-                self.loss_scale *= self.growth_factor
+                self.loss_scale = min(self.loss_scale * self.growth_factor, self.max_scale)
                 self.growth_tracker = 0
         self._scale_t.fill_(self.loss_scale)
         return not overflow
 
     def state_dict(self):
-        return {"loss_scale": self.loss_scale, "growth_tracker": self.growth_tracker,
-                "skipped_steps": self.skipped_steps, "ru3d": "fp16"}
+        """apex's `amp.state_dict()` layout, which the reference checkpoints as 'amp_state_dict' (trainer.py:617-618):
+        {'loss_scaler0': {'loss_scale': float, 'unskipped': int}} - `unskipped` is apex's name for the count of clean
+        steps since the last change of the scale.  The extra key 'ru3d' (skipped-step count, dtype tag) is ignored by
+        apex's loader, which reads only the loss_scaler<i> entries."""
+        return {"loss_scaler0": {"loss_scale": self.loss_scale, "unskipped": self.growth_tracker},
+                "ru3d": {"dtype": "fp16", "skipped_steps": self.skipped_steps}}
 
     def load_state_dict(self, state):
-        if isinstance(state, dict) and "loss_scale" in state:
+        """Reads the apex layout (a checkpoint of the reference) and this class's round-2 flat layout."""
+        if not isinstance(state, dict):
+            return
+        if isinstance(state.get("loss_scaler0"), dict):
+            inner = state["loss_scaler0"]
+            self.loss_scale = float(inner["loss_scale"])
+            self.growth_tracker = int(inner.get("unskipped", 0))
+            extra = state.get("ru3d")
+            self.skipped_steps = int(extra.get("skipped_steps", 0)) if isinstance(extra, dict) else 0
+        elif "loss_scale" in state:
             self.loss_scale = float(state["loss_scale"])
             self.growth_tracker = int(state.get("growth_tracker", 0))
             self.skipped_steps = int(state.get("skipped_steps", 0))
-            if self._scale_t is not None:
-                self._scale_t.fill_(self.loss_scale)
+        else:
+            return
+        self.loss_scale = min(max(self.loss_scale, self.min_scale), self.max_scale)
+        if self._scale_t is not None:
+            self._scale_t.fill_(self.loss_scale)

@@ -72,6 +72,11 @@ class Subset(torch.utils.data.Subset):
         case = self.dataset[self.indices[idx]]
         return self.transform(case) if self.transform else case
 
+    def __getitems__(self, indices):
+        # torch >= 2.0 loaders fetch batches through __getitems__, and the inherited one reads self.dataset directly:
+        # the transform of the reference's class (trainer.py:403-412, written for the per-item protocol) would be skipped
+        return [self[i] for i in indices]
+
 
 def _dist_ready():
     return torch.distributed.is_available() and torch.distributed.is_initialized() \
@@ -261,6 +266,7 @@ class Trainer():
         self._flush(pending, results)
 
         mean_result = {}
+        self._last_batches = len(results)
         if results:
             for key in results[0].keys():
                 mean_result[key] = float(np.mean(np.array([r[key] for r in results])))
@@ -296,14 +302,16 @@ class Trainer():
         self.train_indices, self.valid_indices, self.current_epoch = box
 
     def _epoch_mean_over_ranks(self, result):
-        """Every rank must feed the scheduler and the best-checkpoint rule the same numbers."""
+        """Every rank must feed the scheduler and the best-checkpoint rule the same numbers: the mean over ALL batches of
+        the epoch (sum and count are reduced, not a mean of per-rank means)."""
         if not _dist_ready() or not result:
             return result
         import torch.distributed as dist
         keys = sorted(result.keys())
+        count = float(max(getattr(self, "_last_batches", 1), 0))
         vals = torch.tensor([[result[k] for k in keys]], dtype=torch.float64)
         vals = torch.nan_to_num(vals, nan=0.0)
-        flags = torch.tensor([[0.0 if math.isnan(result[k]) else 1.0 for k in keys]], dtype=torch.float64)
+        flags = torch.tensor([[0.0 if math.isnan(result[k]) else count for k in keys]], dtype=torch.float64)
         both = torch.cat([vals * flags, flags]).to(self.device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(both)
         both = both.cpu()
@@ -311,28 +319,38 @@ class Trainer():
 
     # ------------------------------------------------------------------ loaders
     def _loader(self, indices, transform, num_samples, shuffle):
+        """One process per GPU: the ranks SHARE an epoch (the reference is one process, so an epoch is num_samples draws
+        or one pass over the split, whatever the number of GPUs): rank r draws ceil(num_samples / world) samples from its
+        own stream, or takes every world-th case of one common permutation (wrapped to equal length - every rank must
+        take the same number of steps, the gradient exchange is collective)."""
         subset = Subset(self.dataset, indices, transform)
         kwargs = dict(self.dataloader_kwargs)
-        gen = None
-        if _dist_ready():
-            # same split on every rank, different draws: rank r's sampler stream is seeded from the global seed and r
-            import torch.distributed as dist
-            gen = torch.Generator()
-            gen.manual_seed((torch.initial_seed() + 7919 * (dist.get_rank() + 1) + 104729 * self.current_epoch)
-                            % (1 << 63))
+        if not _dist_ready():
+            if num_samples is not None:
+                sampler = torch.utils.data.RandomSampler(subset, True, num_samples)
+                return torch.utils.data.DataLoader(subset, sampler=sampler, **kwargs)
+            return torch.utils.data.DataLoader(subset, shuffle=shuffle, **kwargs)
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        base = torch.initial_seed() + 104729 * self.current_epoch
         if num_samples is not None:
-            sampler = torch.utils.data.RandomSampler(subset, True, num_samples, generator=gen)
+            gen = torch.Generator()
+            gen.manual_seed((base + 7919 * (rank + 1)) % (1 << 63))      # same split on every rank, different draws
+            sampler = torch.utils.data.RandomSampler(subset, True, -(-num_samples // world), generator=gen)
             return torch.utils.data.DataLoader(subset, sampler=sampler, **kwargs)
-        if _dist_ready() and shuffle is False and len(indices) > 0:
-            # validation without resampling: rank r takes every world-th case; the epoch mean is reduced over ranks
-            import torch.distributed as dist
-            part = list(range(dist.get_rank(), len(subset), dist.get_world_size()))
-            if part:
-                return torch.utils.data.DataLoader(torch.utils.data.Subset(subset, part), shuffle=False, **kwargs)
-        if shuffle and gen is not None:
-            sampler = torch.utils.data.RandomSampler(subset, False, generator=gen)
-            return torch.utils.data.DataLoader(subset, sampler=sampler, **kwargs)
-        return torch.utils.data.DataLoader(subset, shuffle=shuffle, **kwargs)
+        n = len(subset)
+        if n == 0:
+            return torch.utils.data.DataLoader(subset, shuffle=False, **kwargs)
+        if shuffle:
+            gen = torch.Generator()
+            gen.manual_seed(base % (1 << 63))                            # ONE permutation, the same on every rank
+            order = torch.randperm(n, generator=gen).tolist()
+        else:
+            order = list(range(n))
+        per_rank = -(-n // world)
+        order = (order * (-(-per_rank * world // n)))[:per_rank * world]  # wrap: equal step counts on all ranks
+        part = order[rank::world]
+        return torch.utils.data.DataLoader(torch.utils.data.Subset(subset, part), shuffle=False, **kwargs)
 
     # ------------------------------------------------------------------ fit
     def fit(self, *args, num_epochs=None, save_dir=None, use_amp=False, opt_level='O1', **legacy):

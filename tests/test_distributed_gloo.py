@@ -133,6 +133,29 @@ def _trainer_worker(rank, world, port, out):
                        dataloader_kwargs={"num_workers": 0}, progress=False)
         tr.fit(num_epochs=1, save_dir=os.path.join(out, "ckpt"))
         assert tr._grad_sync is not None
+        # the ranks SHARE an epoch: one common permutation cut rank::world (wrapped to equal step counts), or
+        # ceil(num_samples / world) draws per rank; the epoch mean is sum / count over all batches of all ranks
+        seen = []
+        tr.train_transform = lambda case: (seen.append(int(case["id"])), case)[1]
+
+        class Ids(torch.utils.data.Dataset):
+            def __len__(self):
+                return 5
+
+            def __getitem__(self, i):
+                return {"id": i}
+        tr.dataset = Ids()
+        tr.dataloader_kwargs = {"num_workers": 0, "batch_size": 1}
+        for _ in tr._loader(list(range(5)), tr.train_transform, None, True):
+            pass
+        shuffled = list(seen)
+        del seen[:]
+        for _ in tr._loader(list(range(5)), tr.train_transform, 7, True):
+            pass
+        drawn = len(seen)
+        tr._last_batches = 1 + 2 * rank                     # rank 0: 1 batch of mean 1.0, rank 1: 3 batches of mean 5.0
+        mean = tr._epoch_mean_over_ranks({"loss": 1.0 + 4.0 * rank})
+        torch.save({"shuffled": shuffled, "drawn": drawn, "mean": mean}, os.path.join(out, "shard%d.pt" % rank))
         torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(out, "w%d.pt" % rank))
     finally:
         dist.destroy_process_group()
@@ -146,3 +169,8 @@ def test_trainer_uses_gradsync_and_keeps_ranks_in_lockstep(tmp_path):
     for k in w0:
         assert torch.equal(w0[k], w1[k]), k     # different data per rank, identical weights after training
     assert os.path.exists(os.path.join(str(tmp_path), "ckpt-last.pt"))   # rank 0 wrote the checkpoint
+    sh = [torch.load(os.path.join(str(tmp_path), "shard%d.pt" % r), weights_only=False) for r in range(world)]
+    assert len(sh[0]["shuffled"]) == len(sh[1]["shuffled"]) == 3            # 5 cases, 2 ranks: 3 steps each (one wraps)
+    assert sorted(set(sh[0]["shuffled"] + sh[1]["shuffled"])) == [0, 1, 2, 3, 4]
+    assert sh[0]["drawn"] == sh[1]["drawn"] == 4                             # ceil(7 / 2) draws per rank
+    assert abs(sh[0]["mean"]["loss"] - 4.0) < 1e-12 and sh[1]["mean"] == sh[0]["mean"]   # (1 * 1 + 3 * 5) / 4

@@ -115,6 +115,38 @@ def test_other_shape_falls_back_and_replays_continue():
     assert step.graph is None
 
 
+def test_release_returns_the_graph_pool():
+    """GraphedTrainStep.release(): the gradients, the capture stream's workspace, the captured Adam plans and the static
+    buffers all point into the graph's private pool - after release() the allocator is back at what the model, the
+    optimizer state and the batch need (eager steps continue to work)."""
+    import gc
+    import graph as G
+    import _native as N
+    model, opt, crit = _setup(torch.bfloat16)
+    (x, y), = _batches(1)
+    step = G.GraphedTrainStep(model, crit, opt, warmup=1)
+    step(x, y)                                   # eager: Adam moments exist from here on
+    torch.cuda.synchronize()
+    opt.zero_grad(set_to_none=True)
+    N._WS.clear()
+    gc.collect()
+    base = torch.cuda.memory_allocated(DEV)
+    step(x, y)                                   # capture + first replay
+    step(x, y)
+    torch.cuda.synchronize()
+    held = torch.cuda.memory_allocated(DEV)
+    assert held > base + (8 << 20)               # the pool: activations, gradients, workspaces of one step
+    step.release()
+    gc.collect()
+    torch.cuda.synchronize()
+    after = torch.cuda.memory_allocated(DEV)
+    assert after <= base + (1 << 20), (base, held, after)
+    assert not [k for k in opt._plans if k[1]] and all(p.grad is None for p in model.parameters())
+    step(x, y)                                   # a released step captures again on demand
+    assert step.graph is not None
+    step.release()
+
+
 def test_trainer_capture_step_equals_eager_fit():
     """Trainer.fit(capture_step=True): the epoch results and the final weights of the eager loop."""
     import numpy as np

@@ -179,6 +179,50 @@ def test_trainer_fit_checkpoint_resume(tmp_path):
     assert "parameters" in tr.summary((1, 4, 4, 4))
 
 
+def test_subset_applies_its_transform_through_a_dataloader():
+    """reference trainer.py:403-412: Subset.__getitem__ applies the transform.  torch >= 2.0 DataLoaders fetch through
+    __getitems__, which torch.utils.data.Subset implements by reading the wrapped dataset directly - the drop-in class
+    must keep the transform on that route too (also when nested in another Subset, as the rank shards are)."""
+    class Ids(torch.utils.data.Dataset):
+        def __len__(self):
+            return 6
+
+        def __getitem__(self, i):
+            return {"id": i}
+    seen = []
+    sub = T.Subset(Ids(), [5, 3, 1, 0], lambda case: (seen.append(case["id"]), {"id": case["id"] * 10})[1])
+    got = [b["id"].tolist() for b in torch.utils.data.DataLoader(sub, batch_size=2)]
+    assert got == [[50, 30], [10, 0]] and seen == [5, 3, 1, 0]
+    del seen[:]
+    nested = torch.utils.data.Subset(sub, [3, 0])
+    got = [b["id"].tolist() for b in torch.utils.data.DataLoader(nested, batch_size=2)]
+    assert got == [[0, 50]] and seen == [0, 5]
+
+
+def test_loss_scaler_state_is_apex_layout_in_both_directions():
+    """The reference checkpoints apex's amp.state_dict() as 'amp_state_dict' (trainer.py:617-618):
+    {'loss_scaler0': {'loss_scale', 'unskipped'}}.  LossScaler writes that layout, reads it (a reference checkpoint),
+    still reads its own round-2 flat layout, and caps the scale at apex's max_loss_scale = 2**24."""
+    import optim
+    a = optim.LossScaler()
+    a.loss_scale, a.growth_tracker, a.skipped_steps = 1024.0, 17, 3
+    st = a.state_dict()
+    assert st["loss_scaler0"] == {"loss_scale": 1024.0, "unskipped": 17}
+    assert [k for k in st if k.startswith("loss_scaler")] == ["loss_scaler0"]       # what apex's loader iterates over
+    b = optim.LossScaler()
+    b.load_state_dict(st)
+    assert (b.loss_scale, b.growth_tracker, b.skipped_steps) == (1024.0, 17, 3)
+    c = optim.LossScaler()
+    c.load_state_dict({"loss_scaler0": {"loss_scale": 32768.0, "unskipped": 1999}})   # written by the reference
+    assert (c.loss_scale, c.growth_tracker, c.skipped_steps) == (32768.0, 1999, 0)
+    c.load_state_dict({"loss_scale": 512.0, "growth_tracker": 5, "skipped_steps": 2, "ru3d": "fp16"})   # round 2
+    assert (c.loss_scale, c.growth_tracker, c.skipped_steps) == (512.0, 5, 2)
+    c.load_state_dict({"loss_scaler0": {"loss_scale": 2.0 ** 30, "unskipped": 0}})
+    assert c.loss_scale == 2.0 ** 24
+    c.load_state_dict({"ru3d": "bf16"})                                             # a bf16 run's placeholder: ignored
+    assert c.loss_scale == 2.0 ** 24
+
+
 def test_trainer_nan_step_is_skipped_but_applied(tmp_path):
     # reference trainer.py:496 vs 505-506: the optimizer step happens before the NaN test
     tr = _toy_trainer(tmp_path, dataset=_ToyData(4, nan_at=1), valid_split=0.0)
