@@ -639,9 +639,12 @@ static int s1_ksplit(const S1Plan& p, int N, int D, int H, int W, int Cin, int C
     static const int ksplit_mode = getenv("RU3D_CONV_KSPLIT") ? atoi(getenv("RU3D_CONV_KSPLIT")) : 1;
     const int64_t units = p.nblk_pc * (Cout / 32);
     const int nchunks = Cin / 32;
-    if (!ksplit_mode || !p.small || p.nt2 || units >= 256 || nchunks < 2) return 1;
+    // mode 2: aim at two workgroups per CU (the kernel stages, then computes: a second resident workgroup's MFMAs
+    // cover the first one's staging)
+    const int64_t target = (ksplit_mode == 2 || (ksplit_mode == 3 && units >= 256)) ? 512 : 256;   // 3: level-3-like shapes only
+    if (!ksplit_mode || !p.small || p.nt2 || units >= target || nchunks < 2) return 1;
     int ks = 2;
-    while (ks * 2 <= nchunks && units * ks < 256) ks *= 2;
+    while (ks * 2 <= nchunks && units * ks < target) ks *= 2;
     (void)N; (void)D; (void)H; (void)W;
     return ks;
 }
@@ -669,14 +672,14 @@ static int launch_s1_auto(const MfmaConvArgs& a, hipStream_t st) {
     }
     // deep levels are bound by the weight bytes every workgroup pulls into its CU: when 256-voxel tiles x 32-cout
     // slices still give one workgroup per CU, they halve that traffic against the 128-voxel tiles
-    if (!p.nt2 && p.nblk_pc * (a.Cout / 32) >= 256) {
+    const int ks = s1_ksplit(p, a.N, a.D, a.H, a.W, a.Cin, a.Cout);
+    if (ks <= 1 && !p.nt2 && p.nblk_pc * (a.Cout / 32) >= 256) {
         if (p.wclass == 32) return launch_s1<2, 4, 32, 2>(a, false, st);
         if (p.wclass == 16) return launch_s1<2, 8, 16, 2>(a, false, st);
         return launch_s1<4, 8, 8, 2>(a, false, st);
     }
     // still fewer than one workgroup per CU (8^3): keep the 256-voxel x 32-cout tiles and split the 32-channel
     // chunks over gridDim.z; fp32 partials in the caller's workspace, fixed-order reduce with the bias / residual fused
-    const int ks = s1_ksplit(p, a.N, a.D, a.H, a.W, a.Cin, a.Cout);
     if (ks > 1 && (a.ldy % 8) == 0 && (!a.res || (a.ldr % 8) == 0)) {
         const size_t bytes = (size_t)ks * a.N * a.D * a.H * a.W * a.Cout * sizeof(float);
         if (a.ws && a.ws_bytes >= bytes && (((uintptr_t)a.ws) % 16) == 0) {

@@ -49,6 +49,7 @@ struct Slide64Args {
     int flip;
     int cout_total;                       // Cout of the conv (64 per grid.y slice)
     int tiles_h, tiles_w, dsplit, DL, units;
+    int light_last;                       // EDGE: the last column's far W half lies outside the volume (W % 32 in 1..16)
 };
 
 template <int I, int N, typename F>
@@ -81,7 +82,11 @@ __device__ __forceinline__ void mfma16(f32x4& acc, const bf16x8& w, const bf16x8
 // VG = 1: the four waves are four groups of 16 output channels (64 per workgroup), each wave walks both W halves of
 // the column.  VG = 2 (Cout = 32: the decoder's 64 -> 32 conv on the full-resolution level): two channel groups x two
 // voxel groups - a wave owns one W half, so the workgroup still keeps four matrix pipes busy on 32 output channels.
-template <bool HAS_RES, bool HAS_STATS, int VG>
+// EDGE: W is not a multiple of 32 (config 4: 160 x 160 x 80 gives W = 40 on this level): the last column of a row is
+// partly outside the volume.  Its staged pieces already come back as zeros; the epilogue masks stores, residual reads and
+// statistics per voxel, and a W half that lies outside entirely issues no MFMAs (its passes still carry their share of
+// the staging and of the previous plane's epilogue).  A separate instantiation: the W % 32 == 0 code is unchanged.
+template <bool HAS_RES, bool HAS_STATS, int VG, bool EDGE = false>
 __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a) {
     __shared__ __attribute__((aligned(16))) bf16 lds[RING * PLANE];
     __shared__ __attribute__((aligned(16))) bf16 est_s[4 * 128 * EP];   // epilogue patches (stored values), one per wave
@@ -137,8 +142,13 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
             }
             if (lane < 2) {
                 const int c = cg * 16 + lane * 8 + i;
-                dst[c * 2] = s1;
-                dst[c * 2 + 1] = s2;
+                if constexpr (EDGE) {       // heavy-first unit order: a workgroup may come back to a sample (slab rows start at zero)
+                    dst[c * 2] += s1;
+                    dst[c * 2 + 1] += s2;
+                } else {
+                    dst[c * 2] = s1;
+                    dst[c * 2 + 1] = s2;
+                }
             }
         }
     };
@@ -157,13 +167,31 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
     const bool remap = (a.units % 8) == 0 && (G % 8) == 0;
     for (int ui = blockIdx.x; ui < a.units; ui += G) {
         int u = remap ? (ui % 8) * (a.units / 8) + ui / 8 : ui;   // XCD-contiguous deal (see conv_slide.hip)
-        const int tw_i = u % a.tiles_w;
-        u /= a.tiles_w;
+        int tw_i;
+        if (EDGE && a.light_last) {
+            // the last column of a row issues half the MFMAs (its far W half is outside): all full columns first, the light
+            // ones behind them, so that the second round of a launch with 1 < units / workgroups < 2 is made of light units
+            const int heavy = a.units / a.tiles_w * (a.tiles_w - 1);
+            u = ui;
+            if (u < heavy) {
+                tw_i = u % (a.tiles_w - 1);
+                u /= (a.tiles_w - 1);
+            } else {
+                tw_i = a.tiles_w - 1;
+                u -= heavy;
+            }
+        } else {
+            tw_i = u % a.tiles_w;
+            u /= a.tiles_w;
+        }
         const int th_i = u % a.tiles_h;
         u /= a.tiles_h;
         const int dc = u % a.dsplit;
         const int n = u / a.dsplit;
         const int d0 = dc * a.DL, h0 = th_i * TH, w0 = tw_i * TW;
+        const int wlim = a.W - w0;                       // EDGE: voxels of this column's rows inside the volume
+        const bool far_ok = !EDGE || wlim > 16;          // the second W half holds at least one of them
+        const bool wave_ok = !EDGE || VG == 1 || 16 * hfw < wlim;     // VG = 2: this wave's half
 
         // halo pieces of this column as byte offsets inside a plane; a piece outside the volume carries an offset beyond
         // the buffer's range and the buffer load returns zeros, a plane outside the sample is switched off through the
@@ -237,7 +265,15 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
         auto epi_row_load = [&](int p, bf16x8& rv) {
             rv = *reinterpret_cast<const bf16x8*>(est + (32 * p + (lane >> 1)) * EP + (lane & 1) * 8);
         };
+        auto epi_in = [&](int p) {              // EDGE: is the voxel of patch row 32 p + (lane >> 1) inside the volume
+            const int row = 32 * p + (lane >> 1);
+            const int hf = VG == 1 ? (row >> 6) : hfw;
+            return 16 * hf + (row & 15) < wlim;
+        };
         auto epi_row_finish = [&](int sp, int p, const bf16x8& rv, const bf16x8& rres) {
+            if constexpr (EDGE) {
+                if (!epi_in(p)) return;
+            }
             float v[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) v[i] = (float)rv[i];                         // the stored value of conv + bias
@@ -273,7 +309,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
                 if (has_prev) {
 #pragma unroll
                     for (int k = 0; k < NRQ; k++)
-                        rq[k] = *reinterpret_cast<const bf16x8*>(rbase + epi_vox(s - 1, k) * a.ldr);
+                        if (!EDGE || epi_in(k)) rq[k] = *reinterpret_cast<const bf16x8*>(rbase + epi_vox(s - 1, k) * a.ldr);
                 }
             }
             // wait states in front of the inline-asm MFMA block (see conv_slide.hip)
@@ -294,7 +330,11 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
                         constexpr int m = r - kh;
                         if constexpr (m >= 0 && m < TH) {
                             constexpr int f = ((kd * 3 + kh) * 3 + kw) * 2 + ks;
-                            mfma16<(g == 0 && kh == 0)>(acc[m][hf], wreg[f], xq[r]);
+                            if constexpr (!EDGE || (VG == 1 && hf == 0)) {
+                                mfma16<(g == 0 && kh == 0)>(acc[m][hf], wreg[f], xq[r]);
+                            } else {
+                                if (VG == 1 ? far_ok : wave_ok) mfma16<(g == 0 && kh == 0)>(acc[m][hf], wreg[f], xq[r]);
+                            }
                         }
                     });
                     // Finished tiles go to the patch (its rows of the previous plane were consumed in passes 0..14).  Tile
@@ -315,7 +355,8 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
                             epi_write(3, hf);
                         }
                     }
-                    // row r is free: refill it for the next pass
+                    // row r is free: refill it for the next pass (also in front of an EDGE pass that issues no MFMAs: a
+                    // branch around the LDS reads cost more than the reads - 204 against 189 us on 2 x 80 x 80 x 40)
                     if constexpr (q + 1 < NHF * NG) {
                         frag_row(std::integral_constant<int, PH>{}, std::integral_constant<int, q + 1>{}, rc);
                     } else {
@@ -349,7 +390,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
 #pragma unroll
             for (int k = 0; k < NRQ; k++) {
                 const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-                rq[k] = HAS_RES ? *reinterpret_cast<const bf16x8*>(rbase + epi_vox(a.DL - 1, k) * a.ldr) : z8;
+                rq[k] = (HAS_RES && (!EDGE || epi_in(k))) ? *reinterpret_cast<const bf16x8*>(rbase + epi_vox(a.DL - 1, k) * a.ldr) : z8;
             }
             static_for<0, NEP>([&](auto pc) { epi_piece(pc, a.DL - 1, rv, rq); });
         }
@@ -361,12 +402,16 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
 // units = N x dsplit x (H/4) x (W/32) columns of DL = D/dsplit planes, times Cout/64 output slices (grid.y)
 bool slide64_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* out) {
     static const int mode = getenv("RU3D_CONV_SLIDE64") ? atoi(getenv("RU3D_CONV_SLIDE64")) : 1;
-    if (mode == 0 || Cin != 64 || (Cout != 32 && Cout != 64 && Cout != 128) || (H % TH) || (W % TW) || D < 4) return false;
+    if (mode == 0 || Cin != 64 || (Cout != 32 && Cout != 64 && Cout != 128) || (H % TH) || W < 8 || D < 4) return false;
+    static const int edge_mode = getenv("RU3D_SLIDE64_EDGE") ? atoi(getenv("RU3D_SLIDE64_EDGE")) : 1;
+    if ((W % TW) && (!edge_mode || (W % TW) <= 4)) return false;   // a sliver of a last column is not worth a column's work
     // the staging loads address a sample with 30-bit element offsets; the input may sit in a buffer of twice its channels
     // (the decoder's concat): shapes that could exceed that go to the other kernels consistently (launch, slab, workspace)
     if ((int64_t)D * H * W * Cin * 2 >= (1ll << 30)) return false;
     const int ny = Cout == 32 ? 1 : Cout / 64;
-    const int64_t cols = (int64_t)N * (H / TH) * (W / TW);
+    const int tw_n = (W + TW - 1) / TW;
+    const bool light = (W % TW) != 0 && (W % TW) <= 16 && tw_n > 1;
+    const int64_t cols = (int64_t)N * (H / TH) * tw_n;
     int64_t best_cost = -1;
     int best = 0;
     for (int ds = 1; ds <= D / 4; ds++) {
@@ -377,7 +422,14 @@ bool slide64_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan*
         if (units * ny > 0x7fffffff) break;
         int64_t gx = ru3d_get_cu_budget() / ny;
         if (gx > units) gx = units;
-        const int64_t cost = ((units + gx - 1) / gx) * (dl + 4);
+        int64_t cost = ((units + gx - 1) / gx) * (dl + 4);
+        if (light) {
+            // heavy-first order (see the kernel): workgroup 0 carries the longest chain - units 0, gx, 2 gx, ... - of
+            // which those beyond `heavy` issue about half the MFMAs
+            const int64_t heavy = units / tw_n * (tw_n - 1);
+            cost = 0;
+            for (int64_t u = 0; u < units; u += gx) cost += u < heavy ? dl + 4 : (dl * 9) / 16 + 4;
+        }
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
             best = ds;
@@ -390,7 +442,7 @@ bool slide64_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan*
     out->dsplit = best;
     out->DL = D / best;
     out->tiles_h = H / TH;
-    out->tiles_w = W / TW;
+    out->tiles_w = (W + TW - 1) / TW;
     out->units = (int)units;
     int g = units < ru3d_get_cu_budget() / ny ? (int)units : ru3d_get_cu_budget() / ny;
     if ((units % 8) == 0 && g >= 8) g = (g / 8) * 8;
@@ -418,16 +470,23 @@ int conv_slide64_launch(const void* x, const void* w, const float* bias, const v
     a.flip = g.flip;
     a.cout_total = g.Cout;
     a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w; a.dsplit = p.dsplit; a.DL = p.DL; a.units = p.units;
+    a.light_last = (g.Wo % TW) != 0 && (g.Wo % TW) <= 16 && p.tiles_w > 1;
     const dim3 grid(p.grid, p.ny), block(256);
+#define RU3D_S64_LAUNCH(VGV, EDGEV)                                                                                      \
+    do {                                                                                                                 \
+        if (res) hipLaunchKernelGGL((conv3_s1_slide64_kernel<true, false, VGV, EDGEV>), grid, block, 0, st, a);          \
+        else if (stat_slab) hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, true, VGV, EDGEV>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, false, VGV, EDGEV>), grid, block, 0, st, a);             \
+    } while (0)
+    const bool edge = (g.Wo % TW) != 0;
     if (g.Cout == 32) {
-        if (res) hipLaunchKernelGGL((conv3_s1_slide64_kernel<true, false, 2>), grid, block, 0, st, a);
-        else if (stat_slab) hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, true, 2>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, false, 2>), grid, block, 0, st, a);
+        if (edge) RU3D_S64_LAUNCH(2, true);
+        else RU3D_S64_LAUNCH(2, false);
     } else {
-        if (res) hipLaunchKernelGGL((conv3_s1_slide64_kernel<true, false, 1>), grid, block, 0, st, a);
-        else if (stat_slab) hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, true, 1>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, false, 1>), grid, block, 0, st, a);
+        if (edge) RU3D_S64_LAUNCH(1, true);
+        else RU3D_S64_LAUNCH(1, false);
     }
+#undef RU3D_S64_LAUNCH
     return ru3d_check_launch("conv3_s1_slide64");
 }
 

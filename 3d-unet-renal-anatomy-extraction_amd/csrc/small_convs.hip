@@ -148,15 +148,17 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const bf16* __restri
             const int row = (lane >> 2) + 16 * r, part = lane & 3;
             const bf16x8 v = *reinterpret_cast<const bf16x8*>(patch + row * 40 + part * 8);
             const int64_t vox = vrow + (int64_t)(row >> 5) * g.Wo + (row & 31);
-            *reinterpret_cast<bf16x8*>(y + vox * g.ldy + co0 + part * 8) = v;
+            // border tiles of extents that are not multiples of 8 x 32 (160 x 160 x 80: the last column is half empty)
+            if (h0 + 2 * wave + (row >> 5) < g.Ho && w0 + (row & 31) < g.Wo)
+                *reinterpret_cast<bf16x8*>(y + vox * g.ldy + co0 + part * 8) = v;
         }
     }
 }
 
 static bool stem_fwd_mfma_ok(const ConvGeom& g, int dtype) {
     static const int mode = getenv("RU3D_STEM_MFMA") ? atoi(getenv("RU3D_STEM_MFMA")) : 1;
-    return mode && dtype == RU3D_BF16 && (g.Cout % 32) == 0 && (g.Ho % 8) == 0 && (g.Wo % 32) == 0 && g.Do == g.Di &&
-           g.Ho == g.Hi && g.Wo == g.Wi && g.pad == 1 && (g.ldy % 8) == 0;
+    return mode && dtype == RU3D_BF16 && (g.Cout % 32) == 0 && g.Do == g.Di && g.Ho == g.Hi && g.Wo == g.Wi &&
+           g.pad == 1 && (g.ldy % 8) == 0;
 }
 
 bool stem_fwd_eligible(const ConvGeom& g, int dtype, int y_dtype, const void* res) {
@@ -170,7 +172,7 @@ int stem_fwd_launch(const void* x, const void* w, const float* bias, void* y, co
     const int64_t blocks = (total + 255) / 256;
     if (blocks > 0x7fffffff) return ru3d_fail(-1, "stem_fwd: grid too large");
     if (stem_fwd_mfma_ok(g, dtype) && (((uintptr_t)y) % 16) == 0 && (!bias || (((uintptr_t)bias) % 16) == 0)) {
-        const int tiles_h = g.Ho / 8, tiles_w = g.Wo / 32;
+        const int tiles_h = (g.Ho + 7) / 8, tiles_w = (g.Wo + 31) / 32;
         const int64_t ntiles = (int64_t)g.N * g.Do * tiles_h * tiles_w;
         if (ntiles <= 0x7fffffff) {
             const int nb = (int)(ntiles < STEM_FWD_BLOCKS ? ntiles : STEM_FWD_BLOCKS);
@@ -442,8 +444,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const bf16* __rest
             const int c = tid + i * 256;
             const int f = c >> 2, piece = c & 3;
             const int64_t pos = (((int64_t)n * g.Do + d) * g.Ho + h0 + (f >> 5)) * g.Wo + w0 + (f & 31);
-            *reinterpret_cast<bf16x8*>(&ds[f * 32 + piece * 8]) =
-                *reinterpret_cast<const bf16x8*>(dy + pos * g.lddy + co0 + piece * 8);
+            bf16x8 v = {};      // positions of a border tile outside the volume contribute nothing
+            if (h0 + (f >> 5) < g.Ho && w0 + (f & 31) < g.Wo)
+                v = *reinterpret_cast<const bf16x8*>(dy + pos * g.lddy + co0 + piece * 8);
+            *reinterpret_cast<bf16x8*>(&ds[f * 32 + piece * 8]) = v;
         }
         // the three shifted copies of the input patch: xs[kw][kd][r][c] = x[d + kd - 1][h0 + r - 1][w0 + c + kw - 1]
         for (int e = tid; e < 3 * 3 * 10 * 32; e += 256) {
@@ -479,12 +483,11 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const bf16* __rest
 
 static bool stem_wgrad_mfma_ok(const WgradGeom& g, int dtype) {
     static const int mode = getenv("RU3D_STEM_MFMA") ? atoi(getenv("RU3D_STEM_MFMA")) : 1;
-    return mode && dtype == RU3D_BF16 && (g.Ho % 8) == 0 && (g.Wo % 32) == 0 && g.Do == g.Di && g.Ho == g.Hi &&
-           g.Wo == g.Wi && g.pad == 1;
+    return mode && dtype == RU3D_BF16 && g.Do == g.Di && g.Ho == g.Hi && g.Wo == g.Wi && g.pad == 1;
 }
 
 static int stem_mfma_blocks(const WgradGeom& g) {
-    const int64_t ntiles = (int64_t)g.N * g.Do * (g.Ho / 8) * (g.Wo / 32);
+    const int64_t ntiles = (int64_t)g.N * g.Do * ((g.Ho + 7) / 8) * ((g.Wo + 31) / 32);
     return (int)(ntiles < STEM_MF_BLOCKS ? ntiles : STEM_MF_BLOCKS);
 }
 
@@ -509,7 +512,7 @@ int stem_wgrad_launch(const void* x, const void* dy, float* dw, void* ws, size_t
     if (!ws || ws_bytes < stem_wgrad_ws_bytes(g)) return ru3d_fail(-1, "stem_wgrad: workspace too small");
     if (stem_wgrad_mfma_ok(g, dtype)) {
         const int blocks = stem_mfma_blocks(g);
-        const int tiles_h = g.Ho / 8, tiles_w = g.Wo / 32;
+        const int tiles_h = (g.Ho + 7) / 8, tiles_w = (g.Wo + 31) / 32;
         const int64_t ntiles = (int64_t)g.N * g.Do * tiles_h * tiles_w;
         if (ntiles <= 0x7fffffff) {
             hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(blocks, g.Cout / 32), dim3(256), 0, st, (const bf16*)x,

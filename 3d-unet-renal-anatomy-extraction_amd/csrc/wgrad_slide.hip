@@ -34,6 +34,7 @@ struct WSlideArgs {
     int N, D, H, W;
     int Cin, Cout, ldx, lddy;
     int tiles_h, tiles_w, dsplit, DL, units;   // units per (ci, co) pair
+    int light_last;                            // EDGE: the last column's far W half lies outside the volume
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -53,6 +54,10 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// EDGE: W is not a multiple of 32.  The dy positions beyond W read zeros (dvoff); a column whose far W half lies outside
+// altogether skips the MFMAs of the odd k-steps (columns 16..31 of every row) - its staging runs as always - and such
+// light columns are dealt last, so that a launch with between one and two units per workgroup ends on them.
+template <bool EDGE>
 __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
     __shared__ __attribute__((aligned(16))) bf16 lds[4 * XPLANE + 2 * DPLANE];
     bf16* const dbuf = lds + 4 * XPLANE;
@@ -89,8 +94,22 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
 
     for (int u = blockIdx.x; u < a.units; u += gridDim.x) {
         int t = u;
-        const int w0 = (t % a.tiles_w) * TW;
-        t /= a.tiles_w;
+        int tw_i;
+        if (EDGE && a.light_last) {
+            const int heavy = a.units / a.tiles_w * (a.tiles_w - 1);
+            if (t < heavy) {
+                tw_i = t % (a.tiles_w - 1);
+                t /= (a.tiles_w - 1);
+            } else {
+                tw_i = a.tiles_w - 1;
+                t -= heavy;
+            }
+        } else {
+            tw_i = t % a.tiles_w;
+            t /= a.tiles_w;
+        }
+        const int w0 = tw_i * TW;
+        const bool skip_far = EDGE && a.W - w0 <= 16;     // the far half of every row is outside: odd k-steps add zeros
         const int h0 = (t % a.tiles_h) * TH;
         t /= a.tiles_h;
         const int d0 = (t % a.dsplit) * a.DL;
@@ -181,12 +200,19 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
                 constexpr int rowb2 = (((ks + 2) & 15) >> 1) * WW + (((ks + 2) & 15) & 1) * 16;
                 static_for<0, 7>([&](auto tc) {
                     constexpr int t = decltype(tc)::value;
-                    acc[t] = RU3D_MFMA_32X32X16(aq[ks % 3][t], bq[ks % 3], acc[t], 0, 0, 0);
+                    if constexpr (EDGE && (ks & 1)) {
+                        if (!skip_far) acc[t] = RU3D_MFMA_32X32X16(aq[ks % 3][t], bq[ks % 3], acc[t], 0, 0, 0);
+                    } else {
+                        acc[t] = RU3D_MFMA_32X32X16(aq[ks % 3][t], bq[ks % 3], acc[t], 0, 0, 0);
+                    }
                     if constexpr (ks + 2 < 16) {
-                        if constexpr (t == 0) bq[(ks + 2) % 3] = tr_frag(db + ((ks + 2) * 16 + 8 * h) * 32 + lane_off);
-                        const int tap = wave + 4 * t < 27 ? wave + 4 * t : 26;
-                        const int slot = (PH + tap / 9) & 3;
-                        aq[(ks + 2) % 3][t] = tr_frag(lds + slot * XPLANE + (rowb2 + 8 * h) * 32 + toff[t] + lane_off);
+                        // (EDGE: the fragments of a k-step that issues no MFMAs are not fetched either)
+                        if (!(EDGE && ((ks + 2) & 1)) || !skip_far) {
+                            if constexpr (t == 0) bq[(ks + 2) % 3] = tr_frag(db + ((ks + 2) * 16 + 8 * h) * 32 + lane_off);
+                            const int tap = wave + 4 * t < 27 ? wave + 4 * t : 26;
+                            const int slot = (PH + tap / 9) & 3;
+                            aq[(ks + 2) % 3][t] = tr_frag(lds + slot * XPLANE + (rowb2 + 8 * h) * 32 + toff[t] + lane_off);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -234,14 +260,16 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
 // units per pair = N x dsplit x (H/8) x (W/32); G persistent workgroups per pair (= slabs), pairs on grid.y.
 bool wgrad_slide_plan(const WgradGeom& g, WgradSlidePlan* out) {
     static const int mode = getenv("RU3D_WGRAD_SLIDE") ? atoi(getenv("RU3D_WGRAD_SLIDE")) : 1;
-    if (!mode || g.k != 3 || g.stride != 1 || (g.Cin % 32) || (g.Cout % 32) || (g.Ho % TH) || (g.Wo % 16)) return false;
+    if (!mode || g.k != 3 || g.stride != 1 || (g.Cin % 32) || (g.Cout % 32) || (g.Ho % TH) || (g.Wo % 8) || g.Wo < 16) return false;   // dy positions beyond W are masked one by one
     if (g.Do != g.Di || g.Ho != g.Hi || g.Wo != g.Wi || (g.ldx % 8) || (g.lddy % 8)) return false;
     // buffer-descriptor byte offsets of a sample, the top bit marking "outside the volume"
     if ((int64_t)g.Do * g.Ho * g.Wo * (g.ldx > g.lddy ? g.ldx : g.lddy) >= (1ll << 30)) return false;
     const int pairs = (g.Cin / 32) * (g.Cout / 32);
     static const int max_pairs = getenv("RU3D_WGRAD_SLIDE_PAIRS") ? atoi(getenv("RU3D_WGRAD_SLIDE_PAIRS")) : 16;
     if (pairs > max_pairs) return false;
-    const int64_t cols = (int64_t)g.N * (g.Ho / TH) * ((g.Wo + TW - 1) / TW);
+    const int tw_n = (g.Wo + TW - 1) / TW;
+    const bool light = (g.Wo % TW) != 0 && (g.Wo % TW) <= 16 && tw_n > 1;
+    const int64_t cols = (int64_t)g.N * (g.Ho / TH) * tw_n;
     const int gmax = ru3d_get_cu_budget() / pairs;             // one workgroup per CU in total
     int64_t best_cost = -1;
     int best = 0;
@@ -251,7 +279,12 @@ bool wgrad_slide_plan(const WgradGeom& g, WgradSlidePlan* out) {
         if (dl % 4) continue;
         const int64_t units = cols * ds;
         const int64_t gx = units < gmax ? units : gmax;
-        const int64_t cost = ((units + gx - 1) / gx) * (dl + 4);
+        int64_t cost = ((units + gx - 1) / gx) * (dl + 4);
+        if (light) {    // heavy-first deal: workgroup 0 carries the longest chain; light units run half the k-steps
+            const int64_t heavy = units / tw_n * (tw_n - 1);
+            cost = 0;
+            for (int64_t u = 0; u < units; u += gx) cost += u < heavy ? dl + 4 : (dl * 9) / 16 + 4;
+        }
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
             best = ds;
@@ -287,7 +320,9 @@ int wgrad_slide_launch(const void* x, const void* dy, float* dw, void* ws, const
     a.N = g.N; a.D = g.Do; a.H = g.Ho; a.W = g.Wo;
     a.Cin = g.Cin; a.Cout = g.Cout; a.ldx = g.ldx; a.lddy = g.lddy;
     a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w; a.dsplit = p.dsplit; a.DL = p.DL; a.units = p.units;
-    hipLaunchKernelGGL(wgrad3_s1_slide_kernel, dim3(p.G, p.pairs), dim3(256), 0, st, a);
+    a.light_last = (g.Wo % TW) != 0 && (g.Wo % TW) <= 16 && p.tiles_w > 1;
+    if (g.Wo % TW) hipLaunchKernelGGL(wgrad3_s1_slide_kernel<true>, dim3(p.G, p.pairs), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wgrad3_s1_slide_kernel<false>, dim3(p.G, p.pairs), dim3(256), 0, st, a);
     int rc = ru3d_check_launch("wgrad3_s1_slide");
     if (rc) return rc;
     return wgrad_reduce_launch((const float*)ws, dw, p.G, 27, g.Cin, g.Cout, g.s_o, g.s_i, st);

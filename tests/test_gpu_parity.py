@@ -441,6 +441,10 @@ def test_conv_with_channel_pitch_and_odd_extents(dtype):
                                    # W = 16 mod 32 (config 4's 160 x 160 x 80): the sliding kernels' last column is half
                                    # outside the volume - forward + residual, input gradient (32 -> 64 too), weight gradient
                                    (2, 32, 32, 16, 64, 80), (2, 32, 64, 16, 64, 48), (2, 64, 32, 16, 64, 80),
+                                   # the 64-channel sliding kernel's EDGE form (config 4's level 1: W = 40; W = 8 / 24 mod 32):
+                                   # masked stores, a far W half without MFMAs, 64 -> 64 / 128 and 64 -> 32 (wave = W half)
+                                   (2, 64, 64, 16, 40, 40), (2, 64, 128, 8, 32, 56), (2, 64, 32, 16, 32, 40),
+                                   (3, 64, 64, 8, 64, 72),
                                    # deep-level shapes: the LDS-DMA weight gradient (two cout tiles per workgroup), ragged too
                                    (2, 128, 128, 16, 16, 16), (1, 256, 256, 8, 8, 8), (2, 128, 64, 9, 10, 20)])
 def test_mfma_conv_s1_bf16(shape):
@@ -558,7 +562,8 @@ def test_mfma_convtranspose_bf16(cin, cout, dims):
                                    (1, 32, 32, 6, 6, 8), (2, 32, 32, 64, 64, 64), (5, 32, 32, 4, 128, 128),
                                    (3, 32, 32, 16, 64, 64), (2, 32, 64, 32, 64, 64), (2, 64, 64, 64, 64, 64),
                                    (3, 64, 128, 12, 16, 64), (2, 64, 32, 32, 32, 64), (6, 32, 32, 16, 64, 128),
-                                   (2, 32, 32, 16, 64, 80)])      # W = 16 mod 32: the idle half column must not count
+                                   (2, 32, 32, 16, 64, 80),       # W = 16 mod 32: the idle half column must not count
+                                   (2, 64, 64, 16, 40, 40), (2, 64, 32, 16, 32, 40)])   # slide64 EDGE: masked statistics
 def test_conv_fwd_in_fused_statistics(shape):
     """ru3d_conv3d_fwd_in: conv + InstanceNorm statistics.  On the persistent producer/consumer MFMA kernel the
     sums come from the conv epilogue; they must agree with a separate statistics pass over the stored output
@@ -619,10 +624,12 @@ def test_api_rejects_bad_shapes():
         ops.conv_fwd(torch.zeros(1, 8, 4, 4, 4), pw, None, 8, 3, 1)   # CPU tensor: no fallback
 
 
-@pytest.mark.parametrize("dims,cout", [((8, 16, 64), 32), ((5, 24, 32), 64), ((6, 10, 20), 32)])
+@pytest.mark.parametrize("dims,cout", [((8, 16, 64), 32), ((5, 24, 32), 64), ((6, 10, 20), 32), ((3, 16, 80), 32),
+                                       ((4, 13, 40), 64), ((2, 7, 33), 32)])
 def test_stem_conv_bf16(dims, cout):
     """1 -> F stem conv (network.py:541): forward and weight gradient in bf16 vs torch CPU on the rounded operands.
-    The first two shapes take the MFMA weight-gradient kernel (H % 8 == 0, W % 32 == 0), the last the VALU one."""
+    All shapes take the MFMA kernels since round 3: extents that are not multiples of the 8 x 32 tile (config 4's
+    160 x 160 x 80 gives W = 80) run with masked border tiles; the VALU kernels remain for fp32."""
     g = torch.Generator().manual_seed(sum(dims) + cout)
     d, h, w = dims
     xv = torch.randn(2, 1, d, h, w, generator=g)
