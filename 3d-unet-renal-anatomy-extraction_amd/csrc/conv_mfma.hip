@@ -621,6 +621,18 @@ static S1Plan s1_plan(int N, int D, int H, int W, int Cout) {
     S1Plan p;
     const bool can_nt2 = (Cout % 64) == 0;
     p.wclass = W >= 24 ? 32 : (W >= 12 ? 16 : 8);
+    // extents that fit none of the tiles (config 4: 160 x 160 x 80 -> 40 x 40 x 20 on the 128-channel level): the tile
+    // with the least padded volume (RU3D_CONV_TILEFIT=0: the width classes above)
+    static const int fit_mode = getenv("RU3D_CONV_TILEFIT") ? atoi(getenv("RU3D_CONV_TILEFIT")) : 1;
+    if (fit_mode) {
+        const int64_t v32 = (int64_t)cdiv(D, 2) * 2 * cdiv(H, 4) * 4 * cdiv(W, 32) * 32;
+        const int64_t v16 = (int64_t)cdiv(D, 2) * 2 * cdiv(H, 8) * 8 * cdiv(W, 16) * 16;
+        const int64_t v8 = (int64_t)cdiv(D, 4) * 4 * cdiv(H, 8) * 8 * cdiv(W, 8) * 8;
+        const int64_t cur = p.wclass == 32 ? v32 : (p.wclass == 16 ? v16 : v8);
+        // a narrower tile has more halo per voxel: it must save an eighth of the padded volume to be chosen
+        if (p.wclass == 32 && v16 * 8 < cur * 7 && v16 <= v8) p.wclass = 16;
+        else if (p.wclass >= 16 && v8 * 8 < cur * 7) p.wclass = 8;
+    }
     int64_t big;   // workgroups with MT = 2, widest cout slice
     if (p.wclass == 32) big = (int64_t)N * cdiv(D, 2) * cdiv(H, 4) * cdiv(W, 32);
     else if (p.wclass == 16) big = (int64_t)N * cdiv(D, 2) * cdiv(H, 8) * cdiv(W, 16);
@@ -630,7 +642,7 @@ static S1Plan s1_plan(int N, int D, int H, int W, int Cout) {
     p.small = big < 512;
     p.nt2 = can_nt2 && (!p.small || big * 2 >= 1024);
     static const int pc_mode = getenv("RU3D_CONV_PC") ? atoi(getenv("RU3D_CONV_PC")) : 1;   // 0 = off
-    p.pc = !p.small && pc_mode >= 1 && p.wclass >= 16;
+    p.pc = !p.small && pc_mode >= 1 && (p.wclass >= 16 || fit_mode);
     return p;
 }
 
@@ -666,6 +678,7 @@ static int launch_s1_auto(const MfmaConvArgs& a, hipStream_t st) {
     if (!p.small) {
         if (p.pc && p.wclass == 32) return launch_s1_pc<2, 4, 32, 2, false>(a, p.nt2, st);
         if (p.pc && p.wclass == 16) return launch_s1_pc<2, 8, 16, 2, false>(a, p.nt2, st);
+        if (p.pc && p.wclass == 8) return launch_s1_pc<4, 8, 8, 2, false>(a, p.nt2, st);
         if (p.wclass == 32) return launch_s1<2, 4, 32, 2>(a, p.nt2, st);
         if (p.wclass == 16) return launch_s1<2, 8, 16, 2>(a, p.nt2, st);
         return launch_s1<4, 8, 8, 2>(a, p.nt2, st);
