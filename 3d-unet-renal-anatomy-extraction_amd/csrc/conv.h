@@ -120,6 +120,11 @@ int conv_slide_launch(const void* x, const void* w, const float* bias, const voi
 
 // conv_slide64.hip (3x3x3 stride-1, 64 -> 64 / 128 channels: the same design on v_mfma_f32_16x16x32, a wave = 16 couts)
 bool slide64_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan* out);
+// whole-sample form of the deepest level (conv_ws.hip): split-K slices for this geometry (0 = not its shape); the kernel
+// writes fp32 partials [slice][voxel][Cout] for conv_ksplit_reduce_kernel
+int conv_ws_slices(int N, int D, int H, int W, int Cin, int Cout);
+int conv_ws_launch(const void* x, const void* w, float* part, int N, int D, int H, int W, int Cin, int Cout, int ldx,
+                   int flip, int slices, hipStream_t st);
 int conv_slide64_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
                         float* stat_slab, hipStream_t st);
 

@@ -667,12 +667,28 @@ size_t conv_mfma_ws_bytes(const ConvGeom& g) {
     SlidePlan sp;
     if (slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) return 0;
     if (slide64_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) return 0;
+    if (const int wsl = conv_ws_slices(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout))
+        return (size_t)wsl * g.N * g.Do * g.Ho * g.Wo * g.Cout * sizeof(float);
     const S1Plan p = s1_plan(g.N, g.Do, g.Ho, g.Wo, g.Cout);
     const int ks = s1_ksplit(p, g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout);
     return ks > 1 ? (size_t)ks * g.N * g.Do * g.Ho * g.Wo * g.Cout * sizeof(float) : 0;
 }
 
 static int launch_s1_auto(const MfmaConvArgs& a, hipStream_t st) {
+    // the deepest level: whole-sample workgroups that read their weight slice once (conv_ws.hip), then the split-K sum
+    if (const int wsl = conv_ws_slices(a.N, a.D, a.H, a.W, a.Cin, a.Cout)) {
+        const size_t bytes = (size_t)wsl * a.N * a.D * a.H * a.W * a.Cout * sizeof(float);
+        if (!a.stat_slab && a.ws && a.ws_bytes >= bytes && (((uintptr_t)a.ws) % 16) == 0 && (a.ldy % 8) == 0 &&
+            (!a.res || (a.ldr % 8) == 0)) {
+            int rc = conv_ws_launch(a.x, a.w, (float*)a.ws, a.N, a.D, a.H, a.W, a.Cin, a.Cout, a.ldx, a.flip, wsl, st);
+            if (rc) return rc;
+            const int64_t V = (int64_t)a.N * a.D * a.H * a.W;
+            const int64_t groups = V * (a.Cout / 8);
+            hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st,
+                               (const float*)a.ws, wsl, V, a.Cout, a.bias, a.res, a.ldr, a.y, a.ldy);
+            return ru3d_check_launch("conv_ksplit_reduce");
+        }
+    }
     const S1Plan p = s1_plan(a.N, a.D, a.H, a.W, a.Cout);
     if (a.stat_slab && !p.pc) return ru3d_fail(-1, "conv_mfma: fused statistics need the producer/consumer kernel");
     if (!p.small) {

@@ -445,6 +445,10 @@ def test_conv_with_channel_pitch_and_odd_extents(dtype):
                                    # masked stores, a far W half without MFMAs, 64 -> 64 / 128 and 64 -> 32 (wave = W half)
                                    (2, 64, 64, 16, 40, 40), (2, 64, 128, 8, 32, 56), (2, 64, 32, 16, 32, 40),
                                    (3, 64, 64, 8, 64, 72),
+                                   # the whole-sample kernel of the deepest level (conv_ws.hip): 8 slices x 2 chunks, one chunk per
+                                   # slice, the reference patch's 10 x 10 x 5, a last column tile that is partly / wholly idle
+                                   (2, 512, 512, 8, 8, 8), (1, 512, 512, 8, 8, 8), (2, 512, 512, 10, 10, 5), (2, 256, 256, 6, 8, 8),
+                                   (3, 256, 512, 4, 8, 8), (2, 512, 256, 5, 7, 9), (2, 480, 480, 10, 10, 5),   # 15 chunks over 8 slices
                                    # deep-level shapes: the LDS-DMA weight gradient (two cout tiles per workgroup), ragged too
                                    (2, 128, 128, 16, 16, 16), (1, 256, 256, 8, 8, 8), (2, 128, 64, 9, 10, 20)])
 def test_mfma_conv_s1_bf16(shape):

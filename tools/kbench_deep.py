@@ -13,8 +13,11 @@ def timeit(fn, iters=30):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
+flt = sys.argv[1] if len(sys.argv) > 1 else ""
 shapes = [(128, (32, 32, 32)), (256, (16, 16, 16)), (512, (8, 8, 8)), (128, (40, 40, 20)), (256, (20, 20, 10)), (512, (10, 10, 5))]
 for c, (d, h, w) in shapes:
+    if flt and flt != str(c):
+        continue
     x = torch.randn(2, d, h, w, c, device=dev).to(BF).permute(0, 4, 1, 2, 3)
     wt = torch.randn(c, c, 3, 3, 3, device=dev) * 0.02
     b = torch.randn(c, device=dev)
