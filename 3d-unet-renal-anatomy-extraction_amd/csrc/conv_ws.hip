@@ -43,6 +43,7 @@ struct WsArgs {
     int Cin, Cout, ldx;
     int flip;
     int nchunks;                          // 32-channel chunks of Cin, cut into gridDim.y contiguous slices
+    unsigned mWP, mPP, mW, mHW;           // magic multipliers: x / d = (x * m) >> 32 for x < 65536 (d = WP, HP WP, W, H W)
 };
 
 template <int I, int N, typename F>
@@ -72,7 +73,9 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_ws_kernel(WsArgs a) {
     for (int i = 0; i < WS_NSTG; i++) {
         const int c = tid + 256 * i, row = c >> 2;
         const int q = c & 3;
-        const int pw = row % WP, ph = (row / WP) % HP, pd = row / (WP * HP);
+        // (no integer divisions in the prologue)
+        const int pd = (int)__umulhi((unsigned)row, a.mPP), rem = row - pd * (HP * WP);
+        const int ph = (int)__umulhi((unsigned)rem, a.mWP), pw = rem - ph * WP;
         const bool ok = row < PV && pd >= 1 && pd <= a.D && ph >= 1 && ph <= a.H && pw >= 1 && pw <= a.W;
         voff[i] = ok ? ((((pd - 1) * a.H + ph - 1) * a.W + pw - 1) * a.ldx + q * 8) * 2 : (int)0x80000000;
     }
@@ -86,7 +89,8 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_ws_kernel(WsArgs a) {
     for (int t = 0; t < WS_MAXT; t++) {
         int v = (wave + 4 * t) * 16 + (lane & 15);
         if (v >= V) v = 0;                            // idle lanes of the last tile read a valid row; never stored
-        const int w = v % a.W, h = (v / a.W) % a.H, d = v / (a.W * a.H);
+        const int d = (int)__umulhi((unsigned)v, a.mHW), rem = v - d * (a.H * a.W);
+        const int h = (int)__umulhi((unsigned)rem, a.mW), w = rem - h * a.W;
         prow[t] = ((d * HP + h) * WP + w) * WS_PITCH + kb * 8;       // element offset of this lane's k-block in that row
     }
 
@@ -240,6 +244,8 @@ int conv_ws_launch(const void* x, const void* w, float* part, int N, int D, int 
     a.Cin = Cin; a.Cout = Cout; a.ldx = ldx;
     a.flip = flip;
     a.nchunks = Cin / 32;
+    auto magic = [](int d) { return (unsigned)((0x100000000ull / (unsigned)d) + 1); };
+    a.mWP = magic(W + 2); a.mPP = magic((H + 2) * (W + 2)); a.mW = magic(W); a.mHW = magic(H * W);
     if ((int64_t)D * H * W * ldx * 2 >= (1ll << 31)) return ru3d_fail(-1, "conv_ws: sample too large");
     hipLaunchKernelGGL(conv3_s1_ws_kernel, dim3(Cout / 32, slices, N), dim3(256), 0, st, a);
     return ru3d_check_launch("conv3_s1_ws");
