@@ -26,4 +26,4 @@ for c, (d, h, w) in shapes:
     t = timeit(lambda: ops.conv_fwd(x, pf, b, c, 3, 1))
     t2 = timeit(lambda: ops.conv_dgrad(x, pd, tuple(x.shape), 3, 1))
     t3 = timeit(lambda: ops.conv_wgrad(x, x, 3, 1))
-    print("%4d ch %2dx%2dx%2d  fwd %7.1f us (%4.1f%% mfma)  dgrad %7.1f us  wgrad %7.1f us (%4.1f%%)" % (c, d, h, w, t, fl / t / 1e6 / 2.5e15 * 100 * 1e6 / 1e6, t2, t3, fl / t3 / 2.5e9), flush=True)
+    print("%4d ch %2dx%2dx%2d  fwd %7.1f us (%4.1f%% of the MFMA peak)  dgrad %7.1f us  wgrad %7.1f us" % (c, d, h, w, t, fl / (t * 1e-6) / 2.5e15 * 100, t2, t3), flush=True)

@@ -14,8 +14,8 @@ out = {}
 # kbench.py 3 runs three shapes; the 32->32 one is the only user of the <false, false> sliding instantiation with a
 # 65536-thread grid, the averages over the other kernels mix shapes and are reported as such
 for name, sub in (("conv3d k3 s1 32->32 on 2x128^3", ("conv3_s1_slide32_kernel<false, false, false, false>",)),
-                  ("conv3d k3 s1 64->32 on 2x128^3 (sliding 64-channel kernel, Cout = 32 form)", ("conv3_s1_slide64_kernel<false, false, 2>",)),
-                  ("conv3d k3 s1 64->64 on 2x64^3 (sliding 64-channel kernel)", ("conv3_s1_slide64_kernel<false, false, 1>",)),
+                  ("conv3d k3 s1 64->32 on 2x128^3 (sliding 64-channel kernel, Cout = 32 form)", ("conv3_s1_slide64_kernel<false, false, 2, false>",)),
+                  ("conv3d k3 s1 64->64 on 2x64^3 (sliding 64-channel kernel)", ("conv3_s1_slide64_kernel<false, false, 1, false>",)),
                   ("wgrad k3 s1 sliding kernel (32->32, 64->32 @128^3, 64->64 @64^3 mixed)", ("wgrad3_s1_slide_kernel",))):
     fetch, n1 = mean_counter(sys.argv[1], "FETCH_SIZE", sub)
     write, n2 = mean_counter(sys.argv[2], "WRITE_SIZE", sub)
