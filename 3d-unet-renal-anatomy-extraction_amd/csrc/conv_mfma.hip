@@ -1969,6 +1969,15 @@ static void wgrad_tiles(const WgradGeom& g, int* td, int* th, int* tw) {
     if (g.Wo >= 24) { *td = 2; *th = 4; *tw = 32; }
     else if (g.Wo >= 12) { *td = 2; *th = 8; *tw = 16; }
     else { *td = 4; *th = 8; *tw = 8; }
+    // extents that fit none of the tiles (40 x 40 x 20): the tile with the least padded volume, as in s1_plan
+    static const int fit_mode = getenv("RU3D_CONV_TILEFIT") ? atoi(getenv("RU3D_CONV_TILEFIT")) : 1;
+    if (!fit_mode) return;
+    auto cdiv = [](int x, int y) { return (x + y - 1) / y; };
+    auto vol = [&](int a, int b, int c) { return (int64_t)cdiv(g.Do, a) * a * cdiv(g.Ho, b) * b * cdiv(g.Wo, c) * c; };
+    const int64_t cur = vol(*td, *th, *tw);
+    const int64_t v16 = vol(2, 8, 16), v8 = vol(4, 8, 8);
+    if (*tw == 32 && v16 * 8 < cur * 7 && v16 <= v8) { *td = 2; *th = 8; *tw = 16; }
+    else if (*tw >= 16 && v8 * 8 < cur * 7) { *td = 4; *th = 8; *tw = 8; }
 }
 
 static int wgrad_mfma_groups(const WgradGeom& g) {
