@@ -95,6 +95,45 @@ def test_graphed_training_equals_eager(dtype):
     assert ops._drop_counter[0] == STEPS * step.draws > 0      # dropout is on and the host counter kept in step
 
 
+def test_graphed_batchnorm_training_equals_eager():
+    """The BatchNorm variant trains on the native kernels (ops.ResBlockBNFn / UpBNFn), so its step is capturable too:
+    the running averages and num_batches_tracked are device tensors that every replay moves.  Five steps graphed == the
+    same five steps eager: losses, weights, running statistics, batch counts."""
+    def run(graphed):
+        torch.manual_seed(4)
+        model = network.ResAttrBNUnet3D(2, 32, 1, 3).to(DEV)
+        network.set_compute_dtype(model, torch.bfloat16)
+        model.train()
+        opt = optim.Adam(model.parameters(), lr=1e-3)
+        ops._drop_counter[0] = 0
+        crit = L.HybirdLoss()
+        losses = []
+        step = graph.GraphedTrainStep(model, crit, opt, warmup=2) if graphed else None
+        for x, y in _batches(5):
+            if graphed:
+                losses.append(float(step(x, y)))
+            else:
+                opt.zero_grad(set_to_none=True)
+                loss = crit(model(x), y)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        if graphed:
+            assert step.replays == 3
+            step.release()
+        return model, losses
+    m_e, l_e = run(False)
+    m_g, l_g = run(True)
+    assert l_e == l_g, (l_e, l_g)
+    bad = [k for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()) if not torch.equal(a, b)]
+    assert not bad, bad
+    tracked = [v for k, v in m_g.state_dict().items() if k.endswith("num_batches_tracked")]
+    assert tracked and all(int(v) in (5, 10) for v in tracked)       # ResBlocks use their one norm twice per forward
+    moved = [k for k, v in m_g.state_dict().items() if k.endswith("running_mean") and float(v.abs().max()) > 0]
+    assert len(moved) >= 8
+
+
 def test_other_shape_falls_back_and_replays_continue():
     """A batch of another shape (an epoch's short last batch) runs eagerly between replays; the sequence still equals
     the all-eager run, and eager evaluation after the replays sees the updated weights."""
