@@ -252,6 +252,8 @@ def test_conv_dgrad_in_bwd_fused_equals_two_calls(shape):
     r, g = ref.float(), got.float()
     assert torch.isfinite(g).all()
     err = (g - r).abs().max().item()
-    assert err <= 2e-2 * r.abs().max().item() + 1e-3, (err, r.abs().max().item())
+    # one bf16 ulp of the largest element at most (2^-7 relative at the bottom of its binade): the two paths differ in
+    # the summation order of the backward's sums, nothing else
+    assert err <= 2.0 ** -7 * r.abs().max().item() + 1e-6, (err, r.abs().max().item())
     # the bulk is bit-equal: only elements whose value sits on a bf16 rounding boundary may move by one ulp
     assert (g != r).float().mean().item() < 0.02
