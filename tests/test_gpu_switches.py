@@ -53,7 +53,15 @@ def _oracle_grads(kind):
     y = O.phantom_labels(shape[0], shape[2:], 3)
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     loss, logits, grads = O.train_step(w0, x, y, 4, loss_kwargs={"weight_v": [1, 10, 20]})
-    return float(loss), logits.float(), {k: g.float() for k, g in grads.items()}
+    sim = None
+    if kind == "in":        # the oracle's bf16 storage model: what 16-bit inter-kernel tensors cost by themselves
+        O.set_storage(torch.bfloat16)
+        try:
+            _, _, gs = O.train_step(w0, x, y, 4, loss_kwargs={"weight_v": [1, 10, 20]})
+        finally:
+            O.set_storage(None)
+        sim = {k: g.float() for k, g in gs.items()}
+    return float(loss), logits.float(), {k: g.float() for k, g in grads.items()}, sim
 
 
 def _rel(a, b):
@@ -67,11 +75,17 @@ def test_non_default_kernel_switches_against_the_oracle(tmp_path, kind):
     same effect against the oracle's storage model), and two kernel families with different rounding points sit as far
     from each other.  So the yardstick for an alternative family is the default family's own distance to the oracle:
     no tensor may be more than 1.3x + 0.03 further away, and loss / logits must agree closely."""
-    loss_o, logits_o, grads_o = _oracle_grads(kind)
+    loss_o, logits_o, grads_o, grads_sim = _oracle_grads(kind)
     base = _run(str(tmp_path), "base", kind, {})
     assert abs(base["loss"] - loss_o) <= 5e-3
     e_base = {k: _rel(g, grads_o[k]) for k, g in base["grads"].items() if k.endswith("weight")}
     assert len(e_base) >= 50
+    if grads_sim is not None:
+        # the default family itself, on a shape where the stride-2 tile kernels, the pair kernels and the fused tails
+        # engage (the fixtures' 32^3 nets are too small for them): no further from the truth than the storage model
+        for k, eb in e_base.items():
+            es = _rel(grads_sim[k], grads_o[k])
+            assert eb <= 1.3 * es + 0.03, ("default kernels", k, eb, es)
     for i, env in enumerate(SWITCHES[kind]):
         alt = _run(str(tmp_path), "alt%d" % i, kind, env)
         what = "%s %s" % (kind, env)
