@@ -126,7 +126,7 @@ int conv_ws_slices(int N, int D, int H, int W, int Cin, int Cout);
 int conv_ws_launch(const void* x, const void* w, float* part, int N, int D, int H, int W, int Cin, int Cout, int ldx,
                    int flip, int slices, hipStream_t st);
 int conv_slide64_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
-                        float* stat_slab, hipStream_t st);
+                        float* stat_slab, hipStream_t st, const void* bst_act = nullptr, int bst_ld = 0, float slope = 0.f);
 
 // conv_s2.hip (the stride-2 forms of the large levels: LDS-DMA plane ring, producer wave, weights in registers)
 bool convt_s2_tile_eligible(const ConvGeom& g);

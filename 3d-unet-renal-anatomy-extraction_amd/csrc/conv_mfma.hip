@@ -802,9 +802,12 @@ int stats_slab_finalize_launch(const float* slab, int gx, int cb, int N, int C, 
 }
 
 bool mfma_conv_can_fuse_bwd_sums(const ConvGeom& g) {
-    if (!(g.k == 3 && g.stride == 1 && !g.transposed && g.Cin == 32)) return false;
+    if (!(g.k == 3 && g.stride == 1 && !g.transposed)) return false;
     SlidePlan sp;
-    return slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp);
+    if (g.Cin == 32) return slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp);
+    static const int mode64 = getenv("RU3D_DGRAD_IN_FUSE64") ? atoi(getenv("RU3D_DGRAD_IN_FUSE64")) : 1;
+    if (mode64 && g.Cin == 64 && (g.Cout == 64 || g.Cout == 128)) return slide64_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp);
+    return false;
 }
 
 int mfma_conv_bwd_sums_finalize(const ConvGeom& g, const float* slab, float* m12, hipStream_t st) {
@@ -1641,7 +1644,9 @@ int conv_mfma_launch(const void* x, const void* w, const float* bias, const void
             const bool aligned = (g.ldy % 8) == 0 && (!res || (g.ldr % 8) == 0) && aligned_to(y, 16) &&
                                  (!res || aligned_to(res, 16)) && (g.ldx % 8) == 0 && aligned_to(x, 16) &&
                                  (int64_t)g.Do * g.Ho * g.Wo * g.ldx < (1ll << 30);
-            if (aligned) return conv_slide64_launch(x, w, bias, res, y, g, stat_slab, st);
+            if (aligned && (!bst_act || ((bst_ld % 8) == 0 && aligned_to(bst_act, 16))))
+                return conv_slide64_launch(x, w, bias, res, y, g, stat_slab, st, bst_act, bst_ld, slope);
+            if (bst_act) return ru3d_fail(-1, "conv_mfma: the fused backward sums need 16-byte aligned operands");
             if (stat_slab)
                 return ru3d_fail(-1, "conv_mfma: fused statistics need y (and res) 16-byte aligned with a pitch that is "
                                      "a multiple of 8 on this shape");

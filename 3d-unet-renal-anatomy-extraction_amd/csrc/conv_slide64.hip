@@ -49,6 +49,7 @@ struct Slide64Args {
     int flip;
     int cout_total;                       // Cout of the conv (64 per grid.y slice)
     int tiles_h, tiles_w, dsplit, DL, units;
+    float slope, inv_slope;               // HAS_BST: LeakyReLU slope of the activation being differentiated
     int light_last;                       // EDGE: the last column's far W half lies outside the volume (W % 32 in 1..16)
 };
 
@@ -86,8 +87,15 @@ __device__ __forceinline__ void mfma16(f32x4& acc, const bf16x8& w, const bf16x8
 // partly outside the volume.  Its staged pieces already come back as zeros; the epilogue masks stores, residual reads and
 // statistics per voxel, and a W half that lies outside entirely issues no MFMAs (its passes still carry their share of
 // the staging and of the previous plane's epilogue).  A separate instantiation: the W % 32 == 0 code is unchanged.
-template <bool HAS_RES, bool HAS_STATS, int VG, bool EDGE = false>
+// HAS_BST (input-gradient role in front of an InstanceNorm + LeakyReLU backward, as in conv_slide32.hip): the conv output is
+// the gradient wrt the activation a = lrelu(xhat); `res` / `ldr` carry that activation and the row phase takes the two sums
+// the backward needs - sum g' and sum g' xhat with g' = g lrelu'(a), xhat recovered from a - into the statistics slab: the
+// separate reduction pass over (g, a) disappears on the 64-channel level too.  The stored output is g, unchanged.
+template <bool HAS_RES, bool HAS_STATS, int VG, bool EDGE = false, bool HAS_BST = false>
 __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a) {
+    static_assert(!HAS_BST || (!HAS_RES && !HAS_STATS && VG == 1), "backward sums: their own variant of the 64-cout form");
+    constexpr bool SUMS = HAS_STATS || HAS_BST;        // st1 / st2 and the slab are in use
+    constexpr bool LOADS = HAS_RES || HAS_BST;         // a second tensor is read in the row phase
     __shared__ __attribute__((aligned(16))) bf16 lds[RING * PLANE];
     __shared__ __attribute__((aligned(16))) bf16 est_s[4 * 128 * EP];   // epilogue patches (stored values), one per wave
     const int tid = threadIdx.x, lane = tid & 63;
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
     float st1[8], st2[8];
     int cur_n = -1;
     auto stat_flush = [&]() {
-        if (!HAS_STATS || cur_n < 0) return;
+        if (!SUMS || cur_n < 0) return;
         float* dst = a.stat_slab + ((((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * a.N + cur_n) * CB) * 2;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
         load_plane(3);
         __syncthreads();
 
-        if (HAS_STATS && n != cur_n) {
+        if (SUMS && n != cur_n) {
             stat_flush();
             cur_n = n;
 #pragma unroll
@@ -284,6 +292,16 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
                     st2[i] = fmaf(v[i], v[i], st2[i]);
                 }
             }
+            if constexpr (HAS_BST) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float act = (float)rres[i];
+                    const float gp = act > 0.f ? v[i] : v[i] * a.slope;
+                    const float xh = act > 0.f ? act : act * a.inv_slope;
+                    st1[i] += gp;
+                    st2[i] = fmaf(gp, xh, st2[i]);
+                }
+            }
             if constexpr (HAS_RES) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) v[i] += (float)rres[i];
@@ -305,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
             const bool has_prev = s > 0, last = s == a.DL - 1;
             bf16x8 rv;
             bf16x8 rq[NRQ];
-            if constexpr (HAS_RES) {
+            if constexpr (LOADS) {
                 if (has_prev) {
 #pragma unroll
                     for (int k = 0; k < NRQ; k++)
@@ -390,7 +408,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
 #pragma unroll
             for (int k = 0; k < NRQ; k++) {
                 const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-                rq[k] = (HAS_RES && (!EDGE || epi_in(k))) ? *reinterpret_cast<const bf16x8*>(rbase + epi_vox(a.DL - 1, k) * a.ldr) : z8;
+                rq[k] = (LOADS && (!EDGE || epi_in(k))) ? *reinterpret_cast<const bf16x8*>(rbase + epi_vox(a.DL - 1, k) * a.ldr) : z8;
             }
             static_for<0, NEP>([&](auto pc) { epi_piece(pc, a.DL - 1, rv, rq); });
         }
@@ -452,12 +470,14 @@ bool slide64_conv_plan(int N, int D, int H, int W, int Cin, int Cout, SlidePlan*
 }
 
 int conv_slide64_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
-                        float* stat_slab, hipStream_t st) {
+                        float* stat_slab, hipStream_t st, const void* bst_act, int bst_ld, float slope) {
     SlidePlan p;
     if (!slide64_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &p))
         return ru3d_fail(-1, "conv_slide64: shape not supported");
     if ((int64_t)g.Do * g.Ho * g.Wo * g.ldx >= (1ll << 30)) return ru3d_fail(-1, "conv_slide64: sample too large");
     if (res && stat_slab) return ru3d_fail(-1, "conv_slide64: residual and fused statistics cannot be combined");
+    if (bst_act && (res || !stat_slab || g.Cout == 32 || bias))
+        return ru3d_fail(-1, "conv_slide64: backward sums go with a slab, without residual / bias, on the 64-cout form");
     Slide64Args a;
     a.x = (const bf16*)x;
     a.w = (const bf16x8*)w;
@@ -470,6 +490,8 @@ int conv_slide64_launch(const void* x, const void* w, const float* bias, const v
     a.flip = g.flip;
     a.cout_total = g.Cout;
     a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w; a.dsplit = p.dsplit; a.DL = p.DL; a.units = p.units;
+    a.slope = slope; a.inv_slope = slope != 0.f ? 1.f / slope : 0.f;
+    if (bst_act) { a.res = (const bf16*)bst_act; a.ldr = bst_ld; }
     a.light_last = (g.Wo % TW) != 0 && (g.Wo % TW) <= 16 && p.tiles_w > 1;
     const dim3 grid(p.grid, p.ny), block(256);
 #define RU3D_S64_LAUNCH(VGV, EDGEV)                                                                                      \
@@ -479,7 +501,10 @@ int conv_slide64_launch(const void* x, const void* w, const float* bias, const v
         else hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, false, VGV, EDGEV>), grid, block, 0, st, a);             \
     } while (0)
     const bool edge = (g.Wo % TW) != 0;
-    if (g.Cout == 32) {
+    if (bst_act) {
+        if (edge) hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, false, 1, true, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, false, 1, false, true>), grid, block, 0, st, a);
+    } else if (g.Cout == 32) {
         if (edge) RU3D_S64_LAUNCH(2, true);
         else RU3D_S64_LAUNCH(2, false);
     } else {

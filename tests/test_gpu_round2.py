@@ -231,9 +231,11 @@ def test_mfma_packed_weight_is_not_handed_to_the_direct_kernel():
 
 @pytest.mark.parametrize("shape", [(2, 32, 16, 32, 64), (1, 32, 8, 8, 32), (2, 64, 8, 16, 32), (1, 16, 6, 10, 12),
                                    (6, 32, 16, 64, 128),      # columns > workgroups, samples change inside a workgroup
-                                   (2, 32, 16, 64, 80)])      # W = 2.5 columns of 32: the last column's far half idles
+                                   (2, 32, 16, 64, 80),       # W = 2.5 columns of 32: the last column's far half idles
+                                   (2, 64, 16, 64, 64), (3, 64, 8, 64, 96),     # the 64-channel sliding kernel's backward sums
+                                   (2, 64, 16, 32, 40)])      # ... and their EDGE form (masked columns must not count)
 def test_conv_dgrad_in_bwd_fused_equals_two_calls(shape):
-    """ru3d_conv3d_dgrad_in_bwd (the IN + LeakyReLU backward sums taken in the epilogue of the sliding 32-channel conv)
+    """ru3d_conv3d_dgrad_in_bwd (the IN + LeakyReLU backward sums taken in the epilogue of the sliding 32- / 64-channel conv)
     against ru3d_conv3d_dgrad followed by ru3d_in_lrelu_bwd: same da up to the rounding of the sums (fp32 partials per
     wave instead of double partials per block), and the plain two-call path on shapes the fused form does not take."""
     n, c, d, h, w = shape
