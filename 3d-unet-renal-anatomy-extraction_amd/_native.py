@@ -42,7 +42,7 @@ class PatchParams(ctypes.Structure):
                 ("gamma_eps", ctypes.c_float)]
 
 
-PACK_MAX = 12
+PACK_MAX = 40
 _P = ctypes.POINTER(Tensor)
 _vp, _i, _i64, _f, _sz, _u64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t,
                                 ctypes.c_uint64)
@@ -60,6 +60,8 @@ SIGNATURES = {
     "ru3d_conv3d_fwd": (_i, [_P, _vp, _vp, _P, _P, _i, _i, _i, _i, _vp, _sz, _vp]),
     "ru3d_conv3d_fwd_in_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),
     "ru3d_conv3d_fwd_in": (_i, [_P, _vp, _vp, _P, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _f, _vp]),
+    "ru3d_conv3d_fwd_in_lrelu_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),
+    "ru3d_conv3d_fwd_in_lrelu": (_i, [_P, _vp, _vp, _P, _i, _i, _i, _vp, _vp, _vp, _P, _P, _f, _vp, _sz, _f, _vp]),
     "ru3d_conv3d_dgrad": (_i, [_P, _vp, _P, _P, _i, _i, _i, _vp, _sz, _vp]),
     "ru3d_conv3d_s2_pair_fwd_in_supported": (_i, [_P, _P, _P, _i]),
     "ru3d_conv3d_s2_pair_fwd_in_workspace_bytes": (_sz, [_P, _P, _i]),
@@ -70,8 +72,6 @@ SIGNATURES = {
     "ru3d_conv3d_s2_dgrad_pair": (_i, [_P, _vp, _P, _vp, _P, _P, _i, _vp]),
     "ru3d_conv3d_wgrad_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),
     "ru3d_conv3d_wgrad": (_i, [_P, _P, _vp, _vp, _sz, _i, _i, _i, _vp]),
-    "ru3d_wgrad_defer_begin": (_i, [_i]),
-    "ru3d_wgrad_defer_flush": (_i, [_i, _vp]),
     "ru3d_convtranspose3d_k3s2p1_fwd": (_i, [_P, _vp, _vp, _P, _i, _vp]),
     "ru3d_convtranspose3d_k3s2p1_fwd_in_workspace_bytes": (_sz, [_P, _P, _i]),
     "ru3d_convtranspose3d_k3s2p1_fwd_in": (_i, [_P, _vp, _vp, _P, _vp, _vp, _vp, _sz, _f, _i, _vp]),
@@ -126,6 +126,8 @@ SIGNATURES = {
     "ru3d_comm_all_gather": (_i, [_vp, _vp, _i64, _i, _vp]),
     "ru3d_comm_available": (_i, []),
     "ru3d_comm_destroy": (_i, [_vp]),
+    "ru3d_probe_begin": (_i, [_i, _i, _i, _i, _i, _i]),
+    "ru3d_probe_end": (_i, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),
     "ru3d_set_cu_budget": (_i, [_i]),
     "ru3d_get_cu_budget": (_i, []),
     "ru3d_flat_cast": (_i, [_vp, _i, _vp, _i, _i64, _f, _vp]),

@@ -62,6 +62,63 @@ def seg_of(real, have, nseg=1):
     return real // nseg
 
 
+# Training: Unet.forward packs every weight of the pass up front (prepack) - the ~30 per-block launches of a step, most of
+# them 12 us of latency around a few hundred KB, become a handful.  spec key -> (pack, weakref(weight), version, epoch,
+# stream); the blocks' own pack_weights calls find their packs here.
+_PREPACK = {}
+
+
+def _spec_key(sp, code):
+    w, role, stride, cs, ci = sp
+    return (code, w.data_ptr(), tuple(w.shape), role, stride, cs, ci)
+
+
+def _prepacked(specs, code):
+    if not _PREPACK:
+        return None
+    st = None
+    outs = []
+    for sp in specs:
+        hit = _PREPACK.get(_spec_key(sp, code))
+        if hit is None:
+            return None
+        pack, wref, ver, epoch, stream_id = hit
+        w = sp[0]
+        if st is None:
+            st = torch.cuda.current_stream(w.device).cuda_stream
+        if wref() is not w or ver != w._version or epoch != WEIGHTS_EPOCH[0] or stream_id != st:
+            return None
+        outs.append(pack)
+    return outs
+
+
+def prepack(specs, dtype):
+    """Pack every (tensor, role, stride, cout_seg, cin_seg) of `specs` now (duplicates dropped; 3x3x3 weights first, so
+    that the two roles of a weight land in the same launch of the pair kernel) and keep the packs for the pass."""
+    _PREPACK.clear()
+    code = N.dtype_code(dtype)
+    seen, uniq = set(), []
+    for sp in specs:
+        sp = sp if len(sp) == 5 else (sp[0], sp[1], sp[2], 0, 0)
+        k = _spec_key(sp, code)
+        if k not in seen:
+            seen.add(k)
+            uniq.append(sp)
+    if not uniq:
+        return
+
+    def order(sp):
+        w, role = sp[0], sp[1]
+        if role == N.ROLE_BIAS:
+            return (2, 0)
+        return (0 if w.shape[2] == 3 else 1, 0)
+    uniq.sort(key=order)           # stable: both roles of a weight stay adjacent
+    packs = pack_weights(uniq, dtype)
+    st = torch.cuda.current_stream(uniq[0][0].device).cuda_stream
+    for sp, pk in zip(uniq, packs):
+        _PREPACK[_spec_key(sp, code)] = (pk, weakref.ref(sp[0]), sp[0]._version, WEIGHTS_EPOCH[0], st)
+
+
 def pack_weights(specs, dtype):
     """specs: list of (tensor, role, stride[, cout_seg, cin_seg]) -> list of packed tensors, produced by ONE kernel
     launch per RU3D_PACK_MAX items (the packs share one allocation).  role ROLE_BIAS pads a bias vector
@@ -69,6 +126,9 @@ def pack_weights(specs, dtype):
     and reused while the parameters stay where they are (same data pointers)."""
     code = N.dtype_code(dtype)
     specs = [sp if len(sp) == 5 else (sp[0], sp[1], sp[2], 0, 0) for sp in specs]
+    pre = _prepacked(specs, code)
+    if pre is not None:
+        return pre
     key = (code,) + tuple((w.data_ptr(), w.shape, role, stride, cs, ci) for w, role, stride, cs, ci in specs)
     plan = _PACK_PLANS.get(key)
     if plan is None:
@@ -158,36 +218,46 @@ def _conv_out(size, k, s):
 
 
 class Probe:
-    """bench.py: times every launch of ONE conv kernel shape with HIP events recorded on the launch stream
-    (torch's current stream is the stream the C ABI is handed)."""
+    """bench.py: times the main kernel of every 3x3x3 stride-1 conv launch of ONE shape - forward and input gradient,
+    through whichever entry point - with HIP-event pairs the library records on the launch stream right around that
+    kernel (ru3d_probe_begin / _end; not around the memset / finalize / apply launches that share an entry point)."""
 
-    def __init__(self, cin, cout, k, stride, extent):
-        self.key = (cin, cout, k, stride, tuple(extent))
-        self.pairs = []
+    def __init__(self, n, cin, cout, extent):
+        self.key = (int(n),) + tuple(int(e) for e in extent) + (int(cin), int(cout))
+        self.count = 0
+        self.total_ms = 0.0
+        self.active = False
 
-    def match(self, cin, cout, k, stride, extent):
-        return (cin, cout, k, stride, tuple(extent)) == self.key
+    def start(self):
+        check(N.lib.ru3d_probe_begin(*self.key), "probe_begin")
+        self.active = True
 
-    def begin(self):
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        self.pairs.append((e0, e1))
-        return e1
+    def stop(self):
+        if not self.active:
+            return
+        n = ctypes.c_int(0)
+        ms = ctypes.c_double(0.0)
+        check(N.lib.ru3d_probe_end(ctypes.byref(n), ctypes.byref(ms)), "probe_end")
+        self.count += n.value
+        self.total_ms += ms.value
+        self.active = False
 
     def result(self):
-        torch.cuda.synchronize()
-        if not self.pairs:
-            return 0, 0.0
-        total = sum(a.elapsed_time(b) for a, b in self.pairs)
-        return len(self.pairs), total / len(self.pairs)
-
-
-_PROBE = [None]
+        self.stop()
+        return self.count, (self.total_ms / self.count if self.count else 0.0)
 
 
 def set_probe(p):
+    """Arm (a Probe) or disarm (None) the library's kernel probe."""
+    cur = _PROBE[0]
+    if cur is not None and cur is not p:
+        cur.stop()
     _PROBE[0] = p
+    if p is not None:
+        p.start()
+
+
+_PROBE = [None]
 
 
 def _conv_ws(dsrc, ddst, k, stride, dtype, device):
@@ -209,13 +279,9 @@ def conv_fwd(x, pw, bias, cout, k, stride, res=None, out_dtype=None):
     b = _bias(bias)
     dx, dyy = desc(x), desc(y)
     dr = desc(res) if res is not None else None
-    p = _PROBE[0]
-    end = p.begin() if (p is not None and p.match(x.shape[1], cout, k, stride, x.shape[2:])) else None
     ws, wsn = _conv_ws(dx, dyy, k, stride, x.dtype, x.device)
     check(N.lib.ru3d_conv3d_fwd(ref(dx), ptr(pw), ptr(b), ref(dr), ref(dyy), k, stride, N.dtype_code(x.dtype),
                                 N.dtype_code(out_dtype), ws, wsn, stream()), "conv3d_fwd")
-    if end is not None:
-        end.record()
     return y
 
 
@@ -229,13 +295,31 @@ def conv_fwd_in(x, pw, bias, cout, k, stride, drop_scale=None):
     dx, dyy = desc(x), desc(y)
     code = N.dtype_code(x.dtype)
     ws = N.workspace(N.lib.ru3d_conv3d_fwd_in_workspace_bytes(ref(dx), ref(dyy), k, stride, code), x.device)
-    p = _PROBE[0]
-    end = p.begin() if (p is not None and p.match(x.shape[1], cout, k, stride, x.shape[2:])) else None
     check(N.lib.ru3d_conv3d_fwd_in(ref(dx), ptr(pw), ptr(b), ref(dyy), k, stride, code, ptr(drop_scale), ptr(mean),
                                    ptr(scale), ptr(ws), ws.numel(), IN_EPS, stream()), "conv3d_fwd_in")
-    if end is not None:
-        end.record()
     return y, mean, scale
+
+
+def conv_fwd_in_act(x, pw, bias, cout, k, stride, drop_scale=None, res=None, out=None):
+    """conv + InstanceNorm statistics + lrelu(IN(y) (+ res)) behind one entry point (ru3d_conv3d_fwd_in_lrelu): returns
+    (y, mean, scale, act).  One launch for statistics + finalize + apply on the small levels; elsewhere conv_fwd_in +
+    in_lrelu_fwd inside the library."""
+    n, _, d, h, w = x.shape
+    od, oh, ow = _conv_out(d, k, stride), _conv_out(h, k, stride), _conv_out(w, k, stride)
+    y = N.new_act(n, cout, od, oh, ow, x.dtype, x.device)
+    if out is None:
+        out = N.new_act(n, cout, od, oh, ow, x.dtype, x.device)
+    mean = torch.empty(n * cout, dtype=torch.float32, device=x.device)
+    scale = torch.empty(n * cout, dtype=torch.float32, device=x.device)
+    b = _bias(bias)
+    dx, dyy, do = desc(x), desc(y), desc(out)
+    dr = desc(res) if res is not None else None
+    code = N.dtype_code(x.dtype)
+    ws = N.workspace(N.lib.ru3d_conv3d_fwd_in_lrelu_workspace_bytes(ref(dx), ref(dyy), k, stride, code), x.device)
+    check(N.lib.ru3d_conv3d_fwd_in_lrelu(ref(dx), ptr(pw), ptr(b), ref(dyy), k, stride, code, ptr(drop_scale), ptr(mean),
+                                         ptr(scale), ref(dr), ref(do), LRELU_SLOPE, ptr(ws), ws.numel(), IN_EPS, stream()),
+          "conv3d_fwd_in_lrelu")
+    return y, mean, scale, out
 
 
 def conv_dgrad(dy, pw, in_shape, k, stride, res=None):
@@ -243,14 +327,9 @@ def conv_dgrad(dy, pw, in_shape, k, stride, res=None):
     dx = N.new_act(n, cin, d, h, w, dy.dtype, dy.device)
     ddy, ddx = desc(dy), desc(dx)
     dr = desc(res) if res is not None else None
-    p = _PROBE[0]
-    # the stride-1 input gradient runs the same gather kernel as the forward (taps reversed)
-    end = p.begin() if (p is not None and stride == 1 and p.match(dy.shape[1], cin, k, 1, dy.shape[2:])) else None
     ws, wsn = _conv_ws(ddy, ddx, k, stride, dy.dtype, dy.device)
     check(N.lib.ru3d_conv3d_dgrad(ref(ddy), ptr(pw), ref(dr), ref(ddx), k, stride, N.dtype_code(dy.dtype), ws, wsn,
                                   stream()), "conv3d_dgrad")
-    if end is not None:
-        end.record()
     return dx
 
 
@@ -282,46 +361,13 @@ def _grad_out(key, shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
-class DeferredWgrads:
-    """`with DeferredWgrads(dtype, device) as d:` - the weight gradients computed inside (conv_wgrad(..., defer=d)) run
-    their main kernels at once and their fixed-order slab sums as ONE launch on exit (ru3d_wgrad_defer_begin / _flush):
-    a ResBlock's two or three 12-18 us sums overlap instead of queueing.  Every deferred call gets a workspace of its
-    own, kept alive until the flush."""
-
-    def __init__(self, dtype, device, enable=True):
-        self.code = N.dtype_code(dtype)
-        self.device = device
-        self.enable = enable
-        self.keep = []
-
-    def __enter__(self):
-        if self.enable:
-            N.note_device(self.device)
-            check(N.lib.ru3d_wgrad_defer_begin(self.code), "wgrad_defer_begin")
-        return self
-
-    def __exit__(self, *exc):
-        if self.enable:
-            N.note_device(self.device)
-            rc = N.lib.ru3d_wgrad_defer_flush(self.code, stream())      # always: the library must leave the deferred mode
-            self.keep = []
-            if exc[0] is None:
-                check(rc, "wgrad_defer_flush")
-        return False
-
-    def scratch(self, nbytes):
-        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
-        self.keep.append(buf)
-        return buf
-
-
-def conv_wgrad(x, dy, k, stride, key=None, defer=None):
+def conv_wgrad(x, dy, k, stride, key=None):
     cout, cin = dy.shape[1], x.shape[1]
     dw = _grad_out(key, (cout, cin, k, k, k), x.device)
     dx, ddy = desc(x), desc(dy)
     code = N.dtype_code(x.dtype)
     nbytes = N.lib.ru3d_conv3d_wgrad_workspace_bytes(ref(dx), ref(ddy), k, stride, code)
-    ws = defer.scratch(nbytes) if (defer is not None and defer.enable) else N.workspace(nbytes, x.device)
+    ws = N.workspace(nbytes, x.device)
     check(N.lib.ru3d_conv3d_wgrad(ref(dx), ref(ddy), ptr(dw), ptr(ws), ws.numel(), k, stride, code, stream()),
           "conv3d_wgrad")
     return dw
@@ -730,15 +776,19 @@ def as_grad(g, like_dtype):
 
 
 # --------------------------------------------------------------------------- second stream for weight gradients
-# Inside one block's backward the weight gradient of a conv and its input gradient are independent: the wgrad
-# launches (kernel + fixed-order slab reduce) go to a second HIP stream and run beside the dgrad -> InstanceNorm
-# backward chain on the main stream.  On the deep levels (8^3 / 16^3 voxels) neither side fills 256 CUs alone.
-# The join is inside the same backward, so autograd, GradSync hooks and the optimizer only ever see finished
-# gradients on the main stream.  Off by default (RU3D_WGRAD_STREAM=1 enables): at ~550 launches per 28 ms step the extra stream switches cost
-# the host more than the overlap returns; it is kept for graph-captured steps.
-_USE_SIDE = os.environ.get("RU3D_WGRAD_STREAM", "0") == "1"
-_DEFER_WGRAD = os.environ.get("RU3D_WGRAD_DEFER", "0") == "1"      # measured: no gain (the sums are work, not launch latency)
+# Inside one block's backward the weight gradient of a conv and its input gradient are independent: on the SMALL levels
+# (16^3 / 8^3 voxels: kernels of 20-50 us that fill a fraction of the chip) the wgrad launches go to a
+# second HIP stream and run beside the dgrad -> InstanceNorm backward chain on the main stream; under graph capture the
+# fork / join become graph edges.  The join is inside the same backward, so autograd, GradSync hooks and the optimizer
+# only ever see finished gradients on the main stream.  On the large levels the persistent one-workgroup-per-CU kernels
+# cannot share the chip (measured in round 3: 17.2 vs 16.2 ms with everything on the side stream), so the switch is by
+# size: RU3D_WGRAD_STREAM = 0 never, 1 always, unset: when a block's tensors have at most RU3D_SIDE_MAXVOX voxels in all
+# (default 65536 = the 32^3 level at batch 2: 17.10 -> 16.92 ms same box; with the 16^3 / 8^3 levels alone 17.10 -> 17.11 -
+# their kernels are bound by the CUs' L1 / LDS paths, which a concurrent kernel shares).
+_SIDE_MODE = os.environ.get("RU3D_WGRAD_STREAM", "auto")
+_SIDE_MAXVOX = int(os.environ.get("RU3D_SIDE_MAXVOX", "65536"))
 _SIDE = {}
+_SIDE_BUSY = {}      # device -> tensors the side stream still reads (kept alive until the join)
 
 
 def _side_stream(device):
@@ -749,17 +799,21 @@ def _side_stream(device):
 
 
 class _OnSide:
-    """`with _OnSide(device):` - the body's launches are ordered after everything already on the current stream
-    and run on the side stream; `join()` makes the current stream wait for them."""
+    """`with _OnSide(device, nvox, keep):` - the body's launches are ordered after everything already on the current
+    stream and run on the side stream; `_join()` makes the current stream wait for them.  keep: the body's input tensors
+    (allocated on the main stream: they must not return to its allocator before the side stream has read them)."""
 
-    def __init__(self, device):
+    def __init__(self, device, nvox=0, keep=()):
         self.device = device
         self.ctx = None
+        self.on = _SIDE_MODE == "1" or (_SIDE_MODE == "auto" and 0 < nvox <= _SIDE_MAXVOX)
+        self.keep = keep
 
     def __enter__(self):
-        if _USE_SIDE:
+        if self.on:
             side = _side_stream(self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
+            _SIDE_BUSY.setdefault(self.device, []).extend(t for t in self.keep if t is not None)
             self.ctx = torch.cuda.stream(side)
             self.ctx.__enter__()
         return self
@@ -772,13 +826,15 @@ class _OnSide:
 
 
 def _join(device, *outs):
-    if not _USE_SIDE:
+    busy = _SIDE_BUSY.get(device)
+    if busy is None:
         return
     cur = torch.cuda.current_stream(device)
     cur.wait_stream(_side_stream(device))
     for t in outs:
         if t is not None:
             t.record_stream(cur)
+    del _SIDE_BUSY[device]
 
 
 # --------------------------------------------------------------------------- skip connection plumbing
@@ -846,7 +902,7 @@ class ConvFn(torch.autograd.Function):
         cout, cin, cout_seg, cin_seg = ctx.dims
         gy = as_grad(gy, sd)
         gx = gw = gb = None
-        with _OnSide(gy.device):
+        with _OnSide(gy.device):      # stem / head: full-resolution tensors, main stream
             if ctx.needs_input_grad[1]:
                 gw = unpad_wgrad(conv_wgrad(xin, gy, ctx.k, ctx.stride, key=ctx.wkey), cout, cin, cout_seg, cin_seg)
             if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -907,31 +963,34 @@ class ResBlockFn(torch.autograd.Function):
         fused = conv_s2_pair_fwd_in(x, pw1, b1, packs[2], bs, cout_p, drop_scale) if (ws is not None and stride == 2) else None
         if fused is not None:       # pooling block: conv1 + its statistics and the skip conv from one read of x
             y1, mean1, scale1, skip = fused
+            a1 = in_lrelu_fwd(y1, mean1, scale1)
         else:
-            y1, mean1, scale1 = conv_fwd_in(x, pw1, b1, cout_p, 3, stride, drop_scale)
-        a1 = in_lrelu_fwd(y1, mean1, scale1)
-        y2, mean2, scale2 = conv_fwd_in(a1, pw2, b2, cout_p, 3, 1)
-        z = None
-        if fused is not None:
-            pass
-        elif ws is not None:
-            # decoder block: skip conv + IN apply + sum + LeakyReLU in one pass where a kernel exists (no link buffer then:
-            # decoder outputs are not skips)
-            if stride == 1 and out_link is None:
-                z = skip1x1_in_lrelu_fwd(x, packs[2], bs, y2, mean2, scale2)
-            if z is None:
-                skip = conv_fwd(x, packs[2], bs, cout_p, 1, stride)
-        else:
-            skip = x
-        n_, _, d_, h_, w_ = y2.shape
+            y1, mean1, scale1, a1 = conv_fwd_in_act(x, pw1, b1, cout_p, 3, stride, drop_scale)
+        n_, _, d_, h_, w_ = a1.shape
         # in place only when a voxel's channels fill whole 128-byte lines of the interleaved [up | skip] buffer: at 32
         # 16-bit channels every reader of the skip (pool conv, its weight gradient, the norm backward) would pull the
         # other half's lines along - measured slower than the copy it saves
         zout = None
-        if out_link is not None and cout_p * y2.element_size() >= 128:
+        if out_link is not None and cout_p * a1.element_size() >= 128:
             zout = out_link.skip_view(n_, cout_p, d_, h_, w_, sd, x.device)
-        if z is None:
-            z = in_lrelu_fwd(y2, mean2, scale2, res=skip, out=zout)
+        z = None
+        # decoder block on the large levels: skip conv + IN apply + sum + LeakyReLU in one pass, the skip never stored
+        # (no link buffer then: decoder outputs are not skips); the shapes are skip1x1_fused_eligible's
+        tail = (fused is None and ws is not None and stride == 1 and out_link is None and sd != torch.float32
+                and (x.shape[1], cout_p) in ((64, 32), (128, 64)) and n_ * d_ * h_ * w_ >= 65536)
+        if tail:
+            y2, mean2, scale2 = conv_fwd_in(a1, pw2, b2, cout_p, 3, 1)
+            z = skip1x1_in_lrelu_fwd(x, packs[2], bs, y2, mean2, scale2)
+            if z is None:
+                z = in_lrelu_fwd(y2, mean2, scale2, res=conv_fwd(x, packs[2], bs, cout_p, 1, stride), out=zout)
+        else:
+            if fused is not None:
+                pass
+            elif ws is not None:
+                skip = conv_fwd(x, packs[2], bs, cout_p, 1, stride)
+            else:
+                skip = x
+            y2, mean2, scale2, z = conv_fwd_in_act(a1, pw2, b2, cout_p, 3, 1, res=skip, out=zout)
         bwd = packs[nfwd:nw] + [None] * 3
         if checkpoint and train:
             ctx.save_for_backward(x, None, None, None, z, mean1, scale1, mean2, scale2, bwd[0], bwd[1], bwd[2],
@@ -967,34 +1026,27 @@ class ResBlockFn(torch.autograd.Function):
         # sum(gpre) - the skip conv's bias gradient - comes out of the same reduction
         dy2, gpre, gbs_sum = in_lrelu_bwd(gz, z, y2, mean2, scale2, want_gpre=True, want_gpre_sum=True)
         del y2
-        gws = gbs = None
-        # the block's two or three slab sums go out as one launch at the end (not with padded channels: the un-padding
-        # reads the gradient right away; not on the side stream: begin / flush bracket one stream)
-        defer = DeferredWgrads(sd, dev, enable=not (cout_seg or cin_seg) and not _USE_SIDE and _DEFER_WGRAD)
-        defer.__enter__()
-        try:
-            return ResBlockFn._backward_tail(ctx, defer, x, a1, y1, dy2, gpre, gbs_sum, mean1, scale1, pw2d, pw1d, pwsd)
-        finally:
-            defer.__exit__(*__import__("sys").exc_info())
+        return ResBlockFn._backward_tail(ctx, x, a1, y1, dy2, gpre, gbs_sum, mean1, scale1, pw2d, pw1d, pwsd)
 
     @staticmethod
-    def _backward_tail(ctx, defer, x, a1, y1, dy2, gpre, gbs_sum, mean1, scale1, pw2d, pw1d, pwsd):
+    def _backward_tail(ctx, x, a1, y1, dy2, gpre, gbs_sum, mean1, scale1, pw2d, pw1d, pwsd):
         cout, cin, cout_seg, cin_seg = ctx.dims
         dev = x.device
         stride = ctx.stride
         gws = gbs = None
-        with _OnSide(dev):
-            gw2 = unpad_wgrad(conv_wgrad(a1, dy2, 3, 1, key=ctx.wkeys[1], defer=defer), cout, cout, cout_seg, cout_seg)
+        nvox = dy2.shape[0] * dy2.shape[2] * dy2.shape[3] * dy2.shape[4]
+        with _OnSide(dev, nvox, (a1, dy2, x, gpre)):
+            gw2 = unpad_wgrad(conv_wgrad(a1, dy2, 3, 1, key=ctx.wkeys[1]), cout, cout, cout_seg, cout_seg)
             if ctx.has_skip_conv:
-                gws = unpad_wgrad(conv_wgrad(x, gpre, 1, stride, key=ctx.wkeys[2], defer=defer), cout, cin, cout_seg, cin_seg)
+                gws = unpad_wgrad(conv_wgrad(x, gpre, 1, stride, key=ctx.wkeys[2]), cout, cin, cout_seg, cin_seg)
                 gbs = gbs_sum[:cout]
         gb2 = None   # a bias that feeds InstanceNorm has an identically zero gradient: reported as "no gradient"
         # conv2's input gradient and the IN1 + LeakyReLU backward in one call: on the sliding-kernel shapes the backward's
         # sums are taken in the conv's epilogue
         dy1 = conv_dgrad_in_bwd(dy2, pw2d, a1, mean1, scale1)
         del dy2, a1, y1
-        with _OnSide(dev):
-            gw1 = unpad_wgrad(conv_wgrad(x, dy1, 3, stride, key=ctx.wkeys[0], defer=defer), cout, cin, cout_seg, cin_seg)
+        with _OnSide(dev, nvox, (x, dy1)):
+            gw1 = unpad_wgrad(conv_wgrad(x, dy1, 3, stride, key=ctx.wkeys[0]), cout, cin, cout_seg, cin_seg)
         gb1 = None
         gx = None
         need_gx = ctx.needs_input_grad[0]
@@ -1081,7 +1133,8 @@ class UpFn(torch.autograd.Function):
         gu = g[:, :cout_p] if ctx.has_skip else g
         gskip = g[:, cout_p:] if ctx.has_skip else None
         dy, _ = in_lrelu_bwd(gu, u, y, mean, scale, zero_far=True)
-        with _OnSide(x.device):
+        nvox = x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4]
+        with _OnSide(x.device, nvox, (x, dy)):
             # the ConvTranspose3d weight is [Cin][Cout][27]: its outer dimension is the module's in_channels
             gw = unpad_wgrad(convt_wgrad(x, dy, key=ctx.wkey), cin, cout, cin_seg, cout_seg)
             gb = channel_sum(dy)[:cout]

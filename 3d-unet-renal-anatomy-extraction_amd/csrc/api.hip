@@ -310,6 +310,49 @@ extern "C" int ru3d_conv3d_fwd_in(const ru3d_tensor* x, const void* w_packed, co
     return ru3d_instnorm_stats(y, drop_scale, mean, scale, ws, ws_bytes, eps, dtype, stream);
 }
 
+// ---- conv + InstanceNorm statistics + apply (+ residual) + LeakyReLU behind one entry point (reference network.py:
+// 405-416: x = lrelu(IN(dropout(conv1(x)))), lrelu(IN(conv2(x)) + skip)).  On the small levels the statistics, their
+// finalize and the apply are ONE whole-instance kernel (norm_small.hip) that also sums the conv's split-K slices;
+// everywhere else this is ru3d_conv3d_fwd_in followed by ru3d_in_lrelu_fwd.
+static bool small_conv_path(const ru3d_tensor* x, const ru3d_tensor* y, int k, int stride, int dtype) {
+    if (dtype != RU3D_BF16 || k != 3 || stride != 1) return false;
+    const ConvGeom g = fwd_geom(x, y, k, stride);
+    return mfma_conv_eligible(g.Cin, g.Cout, k, dtype, dtype) && mfma_conv_geometry_ok(g) && !mfma_conv_can_fuse_stats(g);
+}
+
+#ifndef RU3D_STORAGE_F16
+extern "C" size_t ru3d_conv3d_fwd_in_lrelu_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* y, int k, int stride,
+                                                           int dtype) {
+    return ru3d_conv3d_fwd_in_workspace_bytes(x, y, k, stride, dtype);
+}
+#endif
+
+extern "C" int ru3d_conv3d_fwd_in_lrelu(const ru3d_tensor* x, const void* w_packed, const float* bias, const ru3d_tensor* y,
+                                        int k, int stride, int dtype, const float* drop_scale, float* mean, float* scale,
+                                        const ru3d_tensor* res, const ru3d_tensor* out, float slope, void* ws,
+                                        size_t ws_bytes, float eps, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_fwd_in_lrelu_f16(x, w_packed, bias, y, k, stride, dtype, drop_scale, mean, scale, res, out, slope, ws, ws_bytes, eps, stream));
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(tensor_ok(x) && tensor_ok(y) && tensor_ok(out) && w_packed && mean && scale && ws,
+                 "conv3d_fwd_in_lrelu: bad argument");
+    RU3D_REQUIRE(res_ok(res, y) && res_ok(out, y), "conv3d_fwd_in_lrelu: res / out do not have the shape of y");
+    const int small = (small_conv_path(x, y, k, stride, dtype) && x->n == y->n && y->d == x->d && y->h == x->h &&
+                       y->w == x->w) ? in_small_mode(y, false, res, out) : 0;
+    if (small) {
+        RU3D_REQUIRE(ws_bytes >= ru3d_conv3d_fwd_in_workspace_bytes(x, y, k, stride, dtype), "conv3d_fwd_in_lrelu: workspace too small");
+        const ConvGeom g = fwd_geom(x, y, k, stride);
+        int ks = 0;      // the whole-instance kernel sums the conv's split-K slices itself; the two-kernel form reads y
+        int rc = conv_mfma_launch(x->ptr, w_packed, bias, nullptr, y->ptr, g, as_stream(stream), nullptr, ws, ws_bytes, nullptr,
+                                  0, 0.f, nullptr, 0, nullptr, small == 1 ? &ks : nullptr);
+        if (rc) return rc;
+        return in_small_fwd_launch(y, ks ? (const float*)ws : nullptr, ks, bias, drop_scale, mean, scale, res, out, ws, eps,
+                                   slope, as_stream(stream));
+    }
+    int rc = ru3d_conv3d_fwd_in(x, w_packed, bias, y, k, stride, dtype, drop_scale, mean, scale, ws, ws_bytes, eps, stream);
+    if (rc) return rc;
+    return ru3d_in_lrelu_fwd(y, mean, scale, res, out, slope, dtype, stream);
+}
+
 extern "C" int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* res,
                                  const ru3d_tensor* dx, int k, int stride, int dtype, void* ws, size_t ws_bytes,
                                  void* stream) {
@@ -509,6 +552,19 @@ extern "C" int ru3d_conv3d_dgrad_in_bwd(const ru3d_tensor* dy, const void* w_pac
         if (rc) return rc;
         return ru3d_in_lrelu_bwd_apply(da, act, mean, scale, m12, dyn, slope, 0, dtype, stream);
     }
+    // the small levels: the whole InstanceNorm backward is one kernel, which also sums the conv's split-K slices (da is
+    // then never stored: nobody else reads it)
+    const int small = (small_conv_path(dy, da, k, stride, dtype) && da->n == dy->n && da->d == dy->d && da->h == dy->h &&
+                       da->w == dy->w) ? in_small_mode(act, false, da, dyn) : 0;
+    if (small) {
+        const ConvGeom g = dgrad_s1_geom(dy, da, k);
+        int ks = 0;
+        int rc = conv_mfma_launch(dy->ptr, w_packed, nullptr, nullptr, da->ptr, g, as_stream(stream), nullptr, ws, ws_bytes,
+                                  nullptr, 0, 0.f, nullptr, 0, nullptr, small == 1 ? &ks : nullptr);
+        if (rc) return rc;
+        return in_small_bwd_launch(da, ks ? (const float*)ws : nullptr, ks, act, act, mean, scale, dyn, nullptr, ws, slope, 0,
+                                   nullptr, as_stream(stream));
+    }
     // not a shape the sliding kernel takes: the two entry points one after the other (they share the workspace in stream order)
     int rc = ru3d_conv3d_dgrad(dy, w_packed, nullptr, da, k, stride, dtype, ws, ws_bytes, stream);
     if (rc) return rc;
@@ -558,16 +614,6 @@ extern "C" int ru3d_conv3d_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, fl
     return wgrad_generic_launch(x->ptr, dy->ptr, dw, ws, ws_bytes, g, dtype, as_stream(stream));
 }
 
-extern "C" int ru3d_wgrad_defer_begin(int dtype) {
-    RU3D_FWD_F16(dtype, ru3d_wgrad_defer_begin_f16(dtype));
-    return wgrad_defer_begin();
-}
-
-extern "C" int ru3d_wgrad_defer_flush(int dtype, void* stream) {
-    RU3D_FWD_F16(dtype, ru3d_wgrad_defer_flush_f16(dtype, stream));
-    Ru3dDeviceGuard dev_guard(stream);
-    return wgrad_defer_flush(as_stream(stream));
-}
 
 // --------------------------------------------------------------------------- ConvTranspose3d(k3,s2,p1) + far pad
 static bool convt_shapes_ok(const ru3d_tensor* x, const ru3d_tensor* y) {

@@ -236,6 +236,78 @@ extern "C" int ru3d_set_cu_budget(int cus) {
 }
 extern "C" int ru3d_get_cu_budget(void) { return g_cu_budget > 0 ? g_cu_budget : 256; }
 
+// ---------------------------------------------------------------- kernel probe (bench.py's roofline figure)
+// HIP-event pairs recorded by the LIBRARY on the launch stream, right around the main kernel of every 3x3x3 stride-1
+// conv launch of one geometry (forward, input gradient, with or without fused statistics / backward sums) - not around
+// the memsets, finalize and apply launches that share an entry point with it.  Off unless ru3d_probe_begin was called.
+#include <mutex>
+#include <vector>
+static std::mutex g_probe_mu;
+static struct {
+    bool on = false;
+    int key[6] = {0, 0, 0, 0, 0, 0};
+    std::vector<hipEvent_t> ev;      // start, stop, start, stop, ...
+} g_probe;
+
+extern "C" int ru3d_probe_begin(int n, int d, int h, int w, int cin, int cout) {
+    std::lock_guard<std::mutex> lk(g_probe_mu);
+    for (hipEvent_t e : g_probe.ev) (void)hipEventDestroy(e);
+    g_probe.ev.clear();
+    const int k[6] = {n, d, h, w, cin, cout};
+    for (int i = 0; i < 6; i++) g_probe.key[i] = k[i];
+    g_probe.on = true;
+    return 0;
+}
+
+extern "C" int ru3d_probe_end(int* launches, double* total_ms) {
+    std::lock_guard<std::mutex> lk(g_probe_mu);
+    g_probe.on = false;
+    int n = 0;
+    double sum = 0.0;
+    for (size_t i = 0; i + 1 < g_probe.ev.size(); i += 2) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_probe.ev[i + 1]) == hipSuccess &&
+            hipEventElapsedTime(&ms, g_probe.ev[i], g_probe.ev[i + 1]) == hipSuccess) {
+            n++;
+            sum += (double)ms;
+        }
+    }
+    (void)hipGetLastError();
+    for (hipEvent_t e : g_probe.ev) (void)hipEventDestroy(e);
+    g_probe.ev.clear();
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = sum;
+    return 0;
+}
+
+// called by the conv launchers (both storage builds): the stop event of a fresh pair whose start was just recorded, or NULL
+void* ru3d_probe_start(int n, int d, int h, int w, int cin, int cout, hipStream_t st) {
+    if (!g_probe.on) return nullptr;
+    std::lock_guard<std::mutex> lk(g_probe_mu);
+    const int k[6] = {n, d, h, w, cin, cout};
+    for (int i = 0; i < 6; i++)
+        if (g_probe.key[i] != k[i]) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {      // events inside a capture cannot be read
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return nullptr;
+    if (hipEventCreate(&e1) != hipSuccess) {
+        (void)hipEventDestroy(e0);
+        return nullptr;
+    }
+    (void)hipEventRecord(e0, st);
+    g_probe.ev.push_back(e0);
+    g_probe.ev.push_back(e1);
+    return (void*)e1;
+}
+
+void ru3d_probe_stop(void* ev, hipStream_t st) {
+    if (ev) (void)hipEventRecord((hipEvent_t)ev, st);
+}
+
 extern "C" int ru3d_comm_destroy(void* comm) {
     if (!comm) return 0;
     Comm* h = (Comm*)comm;

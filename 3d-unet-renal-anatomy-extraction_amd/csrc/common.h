@@ -68,6 +68,10 @@ int ru3d_check_launch(const char* what);         // hipGetLastError -> status
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
+// kernel probe (comm.hip): event pair around the main kernel of a conv launch while ru3d_probe_begin's geometry is armed
+void* ru3d_probe_start(int n, int d, int h, int w, int cin, int cout, hipStream_t st);
+void ru3d_probe_stop(void* ev, hipStream_t st);
+
 // Every launching entry point makes the stream's device current for the duration of the call (PyTorch runs backward
 // on its per-device autograd threads and user code may hold a model on a device other than the thread's current
 // one); a NULL stream means the current device's default stream.  Restores the previous device on exit.

@@ -69,9 +69,6 @@ int pack_generic_launch(const float* src, void* dst, int cin, int cout, int taps
 size_t wgrad_generic_ws_bytes(const WgradGeom& g);
 int wgrad_reduce_launch(const float* part, float* dw, int chunks, int taps, int cin, int cout, int64_t s_o, int64_t s_i,
                         hipStream_t st);
-// deferred slab sums: between begin and flush wgrad_reduce_launch only records its arguments (thread-local)
-int wgrad_defer_begin();
-int wgrad_defer_flush(hipStream_t st);
 int wgrad_generic_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, WgradGeom g, int dtype,
                          hipStream_t st);
 
@@ -84,7 +81,7 @@ int pack_mfma_launch(const float* src, void* dst, int cin, int cout, int taps, i
 int conv_mfma_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
                      hipStream_t st, float* stat_slab = nullptr, void* ws = nullptr, size_t ws_bytes = 0,
                      const void* bst_act = nullptr, int bst_ld = 0, float slope = 0.f, const void* x2 = nullptr,
-                     int ldx2 = 0, const void* w2 = nullptr);
+                     int ldx2 = 0, const void* w2 = nullptr, int* defer_ks = nullptr);
 // y = conv3_dgrad(x) + W2^T x2 in one launch: only the 32-channel sliding kernel has the 28th tap
 bool mfma_conv_can_fuse_partner(const ConvGeom& g);
 size_t conv_mfma_ws_bytes(const ConvGeom& g);
@@ -145,6 +142,18 @@ int conv_s2_tile_launch(const void* x, const void* w, const float* bias, void* y
 bool skip1x1_fused_eligible(const ru3d_tensor* x, const ru3d_tensor* y2, const ru3d_tensor* out, int dtype);
 int skip1x1_fused_launch(const ru3d_tensor* x, const void* w, const float* bias, const ru3d_tensor* y2, const float* mean,
                          const float* scale, const ru3d_tensor* out, float slope, hipStream_t st);
+
+// norm_small.hip (InstanceNorm + LeakyReLU of the small levels).  in_small_mode: 0 = not its shape (norm.hip's three
+// launches), 1 = whole-instance kernel (one launch; can sum a conv's split-K slices itself), 2 = two coalesced kernels.
+int in_small_mode(const ru3d_tensor* y, bool all_samples, const ru3d_tensor* a = nullptr, const ru3d_tensor* b = nullptr,
+                  const ru3d_tensor* c = nullptr, const ru3d_tensor* d = nullptr);
+size_t in_small_ws_bytes(const ru3d_tensor* y);
+int in_small_fwd_launch(const ru3d_tensor* y, const float* part, int ksplit, const float* bias, const float* drop,
+                        float* mean, float* scale, const ru3d_tensor* res, const ru3d_tensor* out, void* ws, float eps,
+                        float slope, hipStream_t st);
+int in_small_bwd_launch(const ru3d_tensor* gout, const float* part, int ksplit, const ru3d_tensor* outp,
+                        const ru3d_tensor* y, const float* mean, const float* scale, const ru3d_tensor* dy,
+                        const ru3d_tensor* gpre, void* ws, float slope, int zero_far, float* gpre_sum, hipStream_t st);
 
 // wgrad_slide.hip (3x3x3 stride-1 weight gradient on the large levels: D-sliding plane ring)
 struct WgradSlidePlan {

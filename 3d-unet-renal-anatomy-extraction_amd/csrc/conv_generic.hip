@@ -503,36 +503,43 @@ __global__ __launch_bounds__(256) void wgrad_generic_kernel(const T* __restrict_
 }
 
 // dw[co*s_o + ci*s_i + tap] = sum_chunk part[chunk][tap][ci][co]
-// block = 64 x (4 consecutive outputs, one 16-byte load) x 4 chunk lanes; each lane keeps 4 independent
-// slab loads in flight; the 4 lane sums are combined in a fixed order -> deterministic.
-__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, float* __restrict__ dw, int chunks,
-                                                  int taps, int cin, int cout, int64_t s_o, int64_t s_i, int bid,
-                                                  f32x4 (*sh)[64]) {
+// block = QX lanes x (4 consecutive outputs, one 16-byte load) x KY = 256 / QX chunk lanes; each lane keeps 4 independent
+// slab loads in flight; the KY lane sums are combined in a fixed order -> deterministic.  QX = 64 / KY = 4 for the usual
+// case; a small output under thousands of slabs (the 1x1x1 skip convs of the large levels: 2 K outputs x 2048 slabs ran
+// 45 us as 8 blocks with 128 dependent rounds each) takes QX = 8 / KY = 32: eight times the blocks, an eighth of the rounds.
+template <int QX>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           int chunks, int taps, int cin, int cout, int64_t s_o,
+                                                           int64_t s_i) {
+    constexpr int KY = 256 / QX;
+    __shared__ f32x4 sh[KY][QX];
     const int64_t total = (int64_t)taps * cin * cout;   // multiple of 4 is NOT required: tail handled scalar
-    const int ox = threadIdx.x & 63, ky = threadIdx.x >> 6;
-    const int64_t i0 = ((int64_t)bid * 64 + ox) * 4;
+    const int ox = threadIdx.x % QX, ky = threadIdx.x / QX;
+    const int64_t i0 = ((int64_t)blockIdx.x * QX + ox) * 4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     const bool full = (i0 + 3 < total) && ((total & 3) == 0);
     if (full) {
         f32x4 s0 = s, s1 = s, s2 = s, s3 = s;
         int c = ky;
-        for (; c + 12 < chunks; c += 16) {
+        for (; c + 3 * KY < chunks; c += 4 * KY) {
             s0 += *reinterpret_cast<const f32x4*>(part + (int64_t)c * total + i0);
-            s1 += *reinterpret_cast<const f32x4*>(part + (int64_t)(c + 4) * total + i0);
-            s2 += *reinterpret_cast<const f32x4*>(part + (int64_t)(c + 8) * total + i0);
-            s3 += *reinterpret_cast<const f32x4*>(part + (int64_t)(c + 12) * total + i0);
+            s1 += *reinterpret_cast<const f32x4*>(part + (int64_t)(c + KY) * total + i0);
+            s2 += *reinterpret_cast<const f32x4*>(part + (int64_t)(c + 2 * KY) * total + i0);
+            s3 += *reinterpret_cast<const f32x4*>(part + (int64_t)(c + 3 * KY) * total + i0);
         }
-        for (; c < chunks; c += 4) s0 += *reinterpret_cast<const f32x4*>(part + (int64_t)c * total + i0);
+        for (; c < chunks; c += KY) s0 += *reinterpret_cast<const f32x4*>(part + (int64_t)c * total + i0);
         s = (s0 + s1) + (s2 + s3);
     } else {
         for (int j = 0; j < 4; j++)
             if (i0 + j < total)
-                for (int c = ky; c < chunks; c += 4) s[j] += part[(int64_t)c * total + i0 + j];
+                for (int c = ky; c < chunks; c += KY) s[j] += part[(int64_t)c * total + i0 + j];
     }
     sh[ky][ox] = s;
     __syncthreads();
     if (ky == 0) {
-        s = (sh[0][ox] + sh[1][ox]) + (sh[2][ox] + sh[3][ox]);
+        s = sh[0][ox];
+#pragma unroll
+        for (int k = 1; k < KY; k++) s += sh[k][ox];
         for (int j = 0; j < 4; j++) {
             const int64_t i = i0 + j;
             if (i >= total) break;
@@ -543,13 +550,6 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
             dw[co * s_o + ci * s_i + tap] = s[j];
         }
     }
-}
-
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                           int chunks, int taps, int cin, int cout, int64_t s_o,
-                                                           int64_t s_i) {
-    __shared__ f32x4 sh[4][64];
-    wgrad_reduce_body(part, dw, chunks, taps, cin, cout, s_o, s_i, blockIdx.x, sh);
 }
 
 // The same sum for the wide layers (Cin*Cout >= 128*128: few slabs, megabytes each), where the write side
@@ -611,81 +611,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tiled_kernel(const float* __
     wgrad_reduce_tiled_body<CO_MAJOR>(part, dw, chunks, taps, cin, cout, s_o, s_i, blockIdx.x, tile);
 }
 
-// Several slab sums in ONE launch (ru3d_wgrad_defer_begin / _flush): a ResBlock's backward produces two or three weight
-// gradients whose slab sums are 12-18 us launches each - latency, not bandwidth; issued together they overlap.
-struct WgradReduceItem {
-    const float* part;
-    float* dw;
-    int chunks, taps, cin, cout;
-    int64_t s_o, s_i;
-    int kind;          // 0: plain, 1: tiled CO_MAJOR, 2: tiled CI_MAJOR
-    int block_base;    // first block of the item in the merged grid
-};
-#define RU3D_DEFER_MAX 8
-struct WgradReduceBatch {
-    int count;
-    WgradReduceItem item[RU3D_DEFER_MAX];
-};
-
-__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgradReduceBatch b) {
-    __shared__ float tile[32 * (4 * 27 + 1)];
-    __shared__ f32x4 sh[4][64];
-    int i = 0;
-    while (i + 1 < b.count && (int)blockIdx.x >= b.item[i + 1].block_base) i++;
-    const WgradReduceItem& it = b.item[i];
-    const int bid = blockIdx.x - it.block_base;
-    if (it.kind == 0) wgrad_reduce_body(it.part, it.dw, it.chunks, it.taps, it.cin, it.cout, it.s_o, it.s_i, bid, sh);
-    else if (it.kind == 1) wgrad_reduce_tiled_body<true>(it.part, it.dw, it.chunks, it.taps, it.cin, it.cout, it.s_o, it.s_i, bid, tile);
-    else wgrad_reduce_tiled_body<false>(it.part, it.dw, it.chunks, it.taps, it.cin, it.cout, it.s_o, it.s_i, bid, tile);
-}
-
-static thread_local struct {
-    bool on = false;
-    WgradReduceBatch batch;
-    int blocks = 0;
-} g_defer;
-
-static int wgrad_reduce_flush(hipStream_t st) {
-    if (g_defer.batch.count == 0) return 0;
-    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)g_defer.blocks), dim3(256), 0, st, g_defer.batch);
-    g_defer.batch.count = 0;
-    g_defer.blocks = 0;
-    return ru3d_check_launch("wgrad_reduce_multi");
-}
-
-int wgrad_defer_begin() {
-    g_defer.on = true;
-    g_defer.batch.count = 0;
-    g_defer.blocks = 0;
-    return 0;
-}
-
-int wgrad_defer_flush(hipStream_t st) {
-    g_defer.on = false;
-    return wgrad_reduce_flush(st);
-}
-
 int wgrad_reduce_launch(const float* part, float* dw, int chunks, int taps, int cin, int cout, int64_t s_o, int64_t s_i,
                         hipStream_t st) {
     const int64_t total = (int64_t)taps * cin * cout;
     const bool tiled = (int64_t)cin * cout >= 128 * 128 && (cin % 4) == 0 && (cout % 32) == 0 && taps <= 27 &&
                        (s_i == taps || s_o == taps);
-    const int64_t blocks = tiled ? (int64_t)(cin / 4) * (cout / 32) : (total + 255) / 256;
-    if (blocks > 0x3fffffff) return ru3d_fail(-1, "wgrad_reduce: grid too large");
-    if (g_defer.on) {
-        // the slabs stay where they are until the flush: the caller gave every deferred weight gradient its own workspace
-        if (g_defer.batch.count == RU3D_DEFER_MAX || (int64_t)g_defer.blocks + blocks > 0x3fffffff) {
-            int rc = wgrad_reduce_flush(st);
-            if (rc) return rc;
-        }
-        WgradReduceItem& it = g_defer.batch.item[g_defer.batch.count++];
-        it.part = part; it.dw = dw; it.chunks = chunks; it.taps = taps; it.cin = cin; it.cout = cout; it.s_o = s_o; it.s_i = s_i;
-        it.kind = tiled ? (s_i == taps ? 1 : 2) : 0;
-        it.block_base = g_defer.blocks;
-        g_defer.blocks += (int)blocks;
-        return 0;
-    }
     if (tiled) {
+        const int64_t blocks = (int64_t)(cin / 4) * (cout / 32);
+        if (blocks > 0x3fffffff) return ru3d_fail(-1, "wgrad_reduce: grid too large");
         if (s_i == taps)
             hipLaunchKernelGGL(wgrad_reduce_tiled_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, part, dw, chunks, taps,
                                cin, cout, s_o, s_i);
@@ -694,8 +627,17 @@ int wgrad_reduce_launch(const float* part, float* dw, int chunks, int taps, int 
                                cin, cout, s_o, s_i);
         return ru3d_check_launch("wgrad_reduce_tiled");
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, dw, chunks, taps, cin, cout,
-                       s_o, s_i);
+    // few outputs under many slabs: more chunk lanes per output (the launch is latency, not bandwidth)
+    const bool deep = chunks >= 128 && (total + 255) / 256 < 512;
+    const int qx = deep ? 8 : 64;
+    const int64_t blocks = (total + 4 * qx - 1) / (4 * qx);
+    if (blocks > 0x3fffffff) return ru3d_fail(-1, "wgrad_reduce: grid too large");
+    if (deep)
+        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, part, dw, chunks, taps, cin, cout,
+                           s_o, s_i);
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, st, part, dw, chunks, taps, cin, cout,
+                           s_o, s_i);
     return ru3d_check_launch("wgrad_reduce");
 }
 

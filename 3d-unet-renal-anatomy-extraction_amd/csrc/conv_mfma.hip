@@ -73,6 +73,9 @@ struct MfmaConvArgs {
     int ksplit;            // number of 32-channel chunk groups (gridDim.z); 1 = none
     void* ws;              // caller-owned workspace for the split-K partials (may be null: no split-K)
     size_t ws_bytes;
+    int* defer_ks;         // host side: leave the split-K partials in ws un-summed and report their count here (0 = y is final)
+    int xcd_cout;          // conv3_s1_mfma_kernel: 1-D launch, every XCD owns a fixed slice of the cout tiles (gy = tiles)
+    int gy, gz;            // cout tiles / split-K slices of that decomposition
 };
 
 // T1 (bijective): consecutive hardware block ids round-robin over the 8 XCDs; give each XCD a contiguous
@@ -98,7 +101,21 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
     __shared__ __attribute__((aligned(16))) bf16 lds[HV * MF_PITCH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int tile = xcd_remap(blockIdx.x, a.nblk);
+    // Deep levels (hundreds of channels on 8^3 / 16^3 voxels): the weights are the big operand.  Hardware workgroup ids
+    // go round-robin over the 8 XCDs, so with `xcd_cout` the launch is 1-D and XCD k takes the cout tiles
+    // [k * gy / 8, (k + 1) * gy / 8) for ALL voxel tiles and split-K slices: its L2 (4 MiB) holds 1/8 of the weight
+    // (1.8 MB of 14 MB at 512 -> 512) and every weight byte leaves HBM once instead of once per voxel tile.
+    int by = blockIdx.y, bz = blockIdx.z, gz = gridDim.z, tile;
+    if (a.xcd_cout) {
+        const int l = blockIdx.x, per = a.gy >> 3, slot = l >> 3;
+        by = (l & 7) * per + slot % per;
+        const int rest = slot / per;
+        tile = rest % a.nblk;
+        bz = rest / a.nblk;
+        gz = a.gz;
+    } else {
+        tile = xcd_remap(blockIdx.x, a.nblk);
+    }
     const int tw_i = tile % a.tiles_w;
     tile /= a.tiles_w;
     const int th_i = tile % a.tiles_h;
@@ -106,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
     const int td_i = tile % a.tiles_d;
     const int n = tile / a.tiles_d;
     const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
-    const int co_blk = blockIdx.y * (NT * 32);
+    const int co_blk = by * (NT * 32);
     const int NTT = a.Cout / 32, KS = a.Cin / 16;
 
     // this lane's output voxels (one per MFMA column tile owned by the wave)
@@ -129,10 +146,10 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[m][t][i] = 0.f;
 
-    const bf16x8* wbase = a.w + (int64_t)blockIdx.y * NT * 64 + lane;
+    const bf16x8* wbase = a.w + (int64_t)by * NT * 64 + lane;
     const int nchunks = a.Cin / 32;
     // split-K: blockIdx.z owns a contiguous run of 32-channel chunks and writes an fp32 partial
-    const int ch_lo = (nchunks * (int)blockIdx.z) / (int)gridDim.z, ch_hi = (nchunks * ((int)blockIdx.z + 1)) / (int)gridDim.z;
+    const int ch_lo = (nchunks * bz) / gz, ch_hi = (nchunks * (bz + 1)) / gz;
     for (int ch = ch_lo; ch < ch_hi; ch++) {
         // ---- weight ring prologue (independent of LDS: its latency hides under the staging below)
         bf16x8 wq[WD][NT];
@@ -209,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
         if (od[m] >= a.D || oh[m] >= a.H || ow[m] >= a.W) continue;
         const int64_t vox = (((int64_t)n * a.D + od[m]) * a.H + oh[m]) * a.W + ow[m];
         if (a.part) {
-            float* pp = a.part + ((int64_t)blockIdx.z * ((int64_t)a.N * a.D * a.H * a.W) + vox) * a.Cout;
+            float* pp = a.part + ((int64_t)bz * ((int64_t)a.N * a.D * a.H * a.W) + vox) * a.Cout;
 #pragma unroll
             for (int t = 0; t < NT; t++)
 #pragma unroll
@@ -591,15 +608,25 @@ static int launch_s1(const MfmaConvArgs& a0, bool nt2, hipStream_t st) {
     if (nblk > 0x7fffffff) return ru3d_fail(-1, "conv_mfma: grid too large");
     a.nblk = (int)nblk;
     const int ks = a.part ? a.ksplit : 1;
+    // RU3D_CONV_XCD: 0 = (tile, cout, split) grid; 1 (default) = XCD-owned cout slices where the weight is the large
+    // operand (split-K shapes); 2 = on every shape of this kernel with a multiple of 8 cout tiles
+    static const int xcd_mode = getenv("RU3D_CONV_XCD") ? atoi(getenv("RU3D_CONV_XCD")) : 1;
+    a.gy = a.Cout / (nt2 ? 64 : 32);
+    a.gz = ks;
+    a.xcd_cout = (xcd_mode == 2 || (xcd_mode == 1 && ks > 1)) && (a.gy % 8) == 0 && nblk * a.gy * ks < 0x7fffffff;
+    dim3 grid((unsigned)nblk, a.gy, ks);
+    if (a.xcd_cout) grid = dim3((unsigned)(nblk * a.gy * ks), 1, 1);
     if (nt2) {
-        dim3 grid((unsigned)nblk, a.Cout / 64, ks);
         hipLaunchKernelGGL((conv3_s1_mfma_kernel<TD, TH, TW, MT, 2>), grid, dim3(256), 0, st, a);
     } else {
-        dim3 grid((unsigned)nblk, a.Cout / 32, ks);
         hipLaunchKernelGGL((conv3_s1_mfma_kernel<TD, TH, TW, MT, 1>), grid, dim3(256), 0, st, a);
     }
     int rc = ru3d_check_launch("conv3_s1_mfma");
     if (rc || !a.part) return rc;
+    if (a.defer_ks) {        // the caller's next kernel sums the slices (norm_small.hip)
+        *a.defer_ks = ks;
+        return 0;
+    }
     const int64_t V = (int64_t)a.N * a.D * a.H * a.W;
     const int64_t groups = V * (a.Cout / 8);
     hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st,
@@ -682,6 +709,10 @@ static int launch_s1_auto(const MfmaConvArgs& a, hipStream_t st) {
             (!a.res || (a.ldr % 8) == 0)) {
             int rc = conv_ws_launch(a.x, a.w, (float*)a.ws, a.N, a.D, a.H, a.W, a.Cin, a.Cout, a.ldx, a.flip, wsl, st);
             if (rc) return rc;
+            if (a.defer_ks) {
+                *a.defer_ks = wsl;
+                return 0;
+            }
             const int64_t V = (int64_t)a.N * a.D * a.H * a.W;
             const int64_t groups = V * (a.Cout / 8);
             hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st,
@@ -1609,9 +1640,28 @@ bool mfma_conv_can_fuse_partner(const ConvGeom& g) {
     return slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp);
 }
 
+static int conv_mfma_launch_inner(const void* x, const void* w, const float* bias, const void* res, void* y,
+                                  const ConvGeom& g, hipStream_t st, float* stat_slab, void* ws, size_t ws_bytes,
+                                  const void* bst_act, int bst_ld, float slope, const void* x2, int ldx2, const void* w2,
+                                  int* defer_ks);
+
 int conv_mfma_launch(const void* x, const void* w, const float* bias, const void* res, void* y, const ConvGeom& g,
                      hipStream_t st, float* stat_slab, void* ws, size_t ws_bytes, const void* bst_act, int bst_ld,
-                     float slope, const void* x2, int ldx2, const void* w2) {
+                     float slope, const void* x2, int ldx2, const void* w2, int* defer_ks) {
+    // bench.py's kernel probe: an event pair around the conv kernel itself (ru3d_probe_begin; comm.hip)
+    void* stop = (g.k == 3 && g.stride == 1 && !g.transposed)
+                     ? ru3d_probe_start(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, st) : nullptr;
+    const int rc = conv_mfma_launch_inner(x, w, bias, res, y, g, st, stat_slab, ws, ws_bytes, bst_act, bst_ld, slope, x2, ldx2,
+                                          w2, defer_ks);
+    ru3d_probe_stop(stop, st);
+    return rc;
+}
+
+static int conv_mfma_launch_inner(const void* x, const void* w, const float* bias, const void* res, void* y,
+                                  const ConvGeom& g, hipStream_t st, float* stat_slab, void* ws, size_t ws_bytes,
+                                  const void* bst_act, int bst_ld, float slope, const void* x2, int ldx2, const void* w2,
+                                  int* defer_ks) {
+    if (defer_ks) *defer_ks = 0;
     if (!mfma_conv_geometry_ok(g)) return ru3d_fail(-1, "conv_mfma: geometry not supported");
     if (x2 && !mfma_conv_can_fuse_partner(g)) return ru3d_fail(-1, "conv_mfma: no fused 1x1 partner for this shape");
     if ((g.ldx % 8) || (g.ldy % 4) || (res && (g.ldr % 4)) || !aligned_to(x, 16) || !aligned_to(y, 8) ||
@@ -1664,6 +1714,9 @@ int conv_mfma_launch(const void* x, const void* w, const float* bias, const void
     a.stat_slab = stat_slab;
     a.part = nullptr;
     a.ksplit = 1;
+    a.xcd_cout = 0;
+    a.gy = a.gz = 1;
+    a.defer_ks = (res || stat_slab) ? nullptr : defer_ks;
     a.ws = ws;
     a.ws_bytes = ws_bytes;
     return launch_s1_auto(a, st);
@@ -1687,6 +1740,7 @@ struct MfmaWgradArgs {
     int Cin, Cout, ldx, lddy;
     int tiles_d, tiles_h, tiles_w, ntiles;
     int G;   // workgroups per channel pair (= number of partial slabs)
+    float* dw;   // G == 1 on the deepest level: the gradient itself, [co][ci][27] (no slab, no reduce pass)
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -1811,6 +1865,40 @@ __global__ __launch_bounds__(256, 2) void wgrad3_s1_mfma_kernel(MfmaWgradArgs a)
         }
         __syncthreads();   // every wave is done with this tile's rows
         if (more) store_tile();
+    }
+    if (a.dw) {
+        // One workgroup holds the pair's whole sum (G == 1: 512 -> 512 on 8^3 has 256 pairs = one workgroup per CU):
+        // the 32 x 32 x 27 block goes out in the parameter's own layout dw[co][ci][tap] - per output channel one run
+        // of 32 * 27 floats - transposed through LDS in four quarters of 8 output channels (row pitch 868 floats:
+        // 16-byte aligned rows, the 8 channel lanes on distinct banks), 16-byte coalesced stores.  No slab, no
+        // reduce pass (was 26 + 18 us per layer).
+        constexpr int RP = 868;
+        static_assert(8 * RP * 4 <= (HV + 256) * 64, "quarter block fits the tile buffer");
+        float* const fl = reinterpret_cast<float*>(lds);
+        const int co_l = lane & 7, qd_mine = (lane & 31) >> 3;
+        for (int qd = 0; qd < 4; qd++) {
+            __syncthreads();   // the tile rows (first quarter) / the previous quarter have been read
+            if (qd_mine == qd) {
+#pragma unroll
+                for (int t = 0; t < 7; t++) {
+                    const int tap = wave + 4 * t;
+                    if (tap < 27) {
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            const int ci_l = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                            fl[co_l * RP + ci_l * 27 + tap] = acc[t][i];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int j = tid; j < 8 * 216; j += 256) {
+                const int c = j / 216, r = j - c * 216;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(fl + c * RP + r * 4);
+                *reinterpret_cast<f32x4*>(a.dw + ((int64_t)(cot * 32 + qd * 8 + c) * a.Cin + cit * 32) * 27 + r * 4) = v;
+            }
+        }
+        return;
     }
     // partial slab: part[((chunk * 27 + tap) * Cin + ci) * Cout + co]; D row = ci, col = co
 #pragma unroll
@@ -1994,6 +2082,10 @@ static int wgrad_mfma_groups(const WgradGeom& g) {
     int64_t G = wg_blocks / pairs;
     if (G < 1) G = 1;
     if (G > ntiles) G = ntiles;
+    // one workgroup per CU already and few tiles each (512 -> 512 on 8^3: 256 pairs x 4 tiles): a single workgroup per
+    // pair writes the gradient itself (RU3D_WGRAD_DIRECT=0: two slabs + the reduce pass)
+    static const int direct = getenv("RU3D_WGRAD_DIRECT") ? atoi(getenv("RU3D_WGRAD_DIRECT")) : 1;
+    if (direct && pairs >= 224 && ntiles <= 8) G = 1;
     return (int)G;
 }
 
@@ -2063,6 +2155,8 @@ int wgrad_mfma_launch(const void* x, const void* dy, float* dw, void* ws, size_t
     a.tiles_w = (g.Wo + tw - 1) / tw;
     a.ntiles = g.N * a.tiles_d * a.tiles_h * a.tiles_w;
     a.G = wgrad_mfma_groups(g);
+    // the gradient in the Conv3d layout [co][ci][27], 16-byte aligned: a lone workgroup per pair stores it directly
+    a.dw = (a.G == 1 && g.s_i == 27 && g.s_o == (int64_t)g.Cin * 27 && aligned_to(dw, 16)) ? dw : nullptr;
     dim3 grid(a.G, (g.Cin / 32) * (g.Cout / 32));
     if (tw == 32)
         hipLaunchKernelGGL((wgrad3_s1_mfma_kernel<2, 4, 32>), grid, dim3(256), 0, st, a);
@@ -2071,7 +2165,7 @@ int wgrad_mfma_launch(const void* x, const void* dy, float* dw, void* ws, size_t
     else
         hipLaunchKernelGGL((wgrad3_s1_mfma_kernel<4, 8, 8>), grid, dim3(256), 0, st, a);
     int rc = ru3d_check_launch("wgrad3_s1_mfma");
-    if (rc) return rc;
+    if (rc || a.dw) return rc;
     return wgrad_reduce_launch((const float*)ws, dw, a.G, 27, g.Cin, g.Cout, g.s_o, g.s_i, st);
 }
 

@@ -10,6 +10,7 @@
     X(ru3d_conv3d_fwd) \
     X(ru3d_conv3d_fwd_in_workspace_bytes) \
     X(ru3d_conv3d_fwd_in) \
+    X(ru3d_conv3d_fwd_in_lrelu) \
     X(ru3d_conv3d_dgrad) \
     X(ru3d_conv3d_s2_pair_fwd_in_supported) \
     X(ru3d_conv3d_s2_pair_fwd_in_workspace_bytes) \
@@ -25,8 +26,6 @@
     X(ru3d_in_lrelu_bwd_apply) \
     X(ru3d_conv3d_wgrad_workspace_bytes) \
     X(ru3d_conv3d_wgrad) \
-    X(ru3d_wgrad_defer_begin) \
-    X(ru3d_wgrad_defer_flush) \
     X(ru3d_convtranspose3d_k3s2p1_fwd) \
     X(ru3d_convtranspose3d_k3s2p1_dgrad) \
     X(ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes) \
@@ -56,6 +55,7 @@
 #define ru3d_conv3d_fwd ru3d_conv3d_fwd_f16
 #define ru3d_conv3d_fwd_in_workspace_bytes ru3d_conv3d_fwd_in_workspace_bytes_f16
 #define ru3d_conv3d_fwd_in ru3d_conv3d_fwd_in_f16
+#define ru3d_conv3d_fwd_in_lrelu ru3d_conv3d_fwd_in_lrelu_f16
 #define ru3d_conv3d_dgrad ru3d_conv3d_dgrad_f16
 #define ru3d_conv3d_s2_pair_fwd_in_supported ru3d_conv3d_s2_pair_fwd_in_supported_f16
 #define ru3d_conv3d_s2_pair_fwd_in_workspace_bytes ru3d_conv3d_s2_pair_fwd_in_workspace_bytes_f16
@@ -71,8 +71,6 @@
 #define ru3d_in_lrelu_bwd_apply ru3d_in_lrelu_bwd_apply_f16
 #define ru3d_conv3d_wgrad_workspace_bytes ru3d_conv3d_wgrad_workspace_bytes_f16
 #define ru3d_conv3d_wgrad ru3d_conv3d_wgrad_f16
-#define ru3d_wgrad_defer_begin ru3d_wgrad_defer_begin_f16
-#define ru3d_wgrad_defer_flush ru3d_wgrad_defer_flush_f16
 #define ru3d_convtranspose3d_k3s2p1_fwd ru3d_convtranspose3d_k3s2p1_fwd_f16
 #define ru3d_convtranspose3d_k3s2p1_dgrad ru3d_convtranspose3d_k3s2p1_dgrad_f16
 #define ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes_f16

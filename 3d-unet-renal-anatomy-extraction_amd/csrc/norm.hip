@@ -7,6 +7,7 @@
 // of 256 threads owns Gb <= 256 channel groups x vpb = 256/Gb voxel lanes and walks a span of voxels.
 // grid = (chunks, N, group blocks).
 #include "common.h"
+#include "conv.h"
 #include <initializer_list>
 
 namespace RU3D_NS {
@@ -591,6 +592,9 @@ extern "C" int ru3d_in_lrelu_bwd(const ru3d_tensor* gout, const ru3d_tensor* out
     RU3D_REQUIRE(ws_bytes >= reduce_ws_bytes(y), "in_lrelu_bwd: workspace too small (%zu < %zu)", ws_bytes,
                  reduce_ws_bytes(y));
     RU3D_REQUIRE((int64_t)y->d * y->h * y->w < (1ll << 31), "in_lrelu_bwd: sample too large");
+    // the small levels: one launch instead of three (norm_small.hip)
+    if (dtype == RU3D_BF16 && in_small_mode(out, gpre_sum != nullptr, gout, y, dy, gpre))
+        return in_small_bwd_launch(gout, nullptr, 0, out, y, mean, scale, dy, gpre, ws, slope, zero_far, gpre_sum, as_stream(stream));
     if (dtype == RU3D_F32)
         return in_bwd_impl<float>(gout, out, y, mean, scale, dy, gpre, ws, slope, zero_far, gpre_sum, as_stream(stream));
     if (dtype == RU3D_BF16)

@@ -134,8 +134,13 @@ class GraphedTrainStep:
         if self.graph is not None:
             self.optimizer.zero_grad(set_to_none=True)
             sid = self.stream.cuda_stream
-            for key in [k for k in N._WS if k[1] == sid]:
+            # the side stream of the small levels' weight gradients (ops._OnSide) joined the capture: its workspace sits
+            # in the pool too, and so do the packed weights of the last pass (ops.prepack)
+            side = _ops._SIDE.get(self.stream.device)
+            sids = (sid,) if side is None else (sid, side.cuda_stream)
+            for key in [k for k in N._WS if k[1] in sids]:
                 del N._WS[key]
+            _ops._PREPACK.clear()
             for name in ("x", "y", "loss", "logits", "_static_logits", "block", "drop_base", "hyper", "host", "host_ev",
                          "stream"):
                 if hasattr(self, name):

@@ -264,6 +264,17 @@ class ConvTrans3D(nn.Module):
         self._bn_eval = _is_plain_bn(self.up[2]) and _is_plain_lrelu(self.up[3])   # native in inference mode only
         self._pad = False          # set by Unet: activations carry channels zero-padded to multiples of 32
 
+    def _pack_specs(self):
+        """The packed forms ops.UpFn asks for in a training pass."""
+        wt, bt = self.up[0].weight, self.up[0].bias
+        cin, cout = wt.shape[0], wt.shape[1]
+        cin_seg = cin if self._pad else 0
+        cout_seg = cout if self._pad else 0
+        specs = [(wt, N.ROLE_CONVT_FWD, 2, cout_seg, cin_seg), (wt, N.ROLE_CONVT_DGRAD, 2, cout_seg, cin_seg)]
+        if cout_seg and bt is not None:
+            specs.append((bt, N.ROLE_BIAS, 1, cout_seg, 0))
+        return specs
+
     def forward(self, x, skip=None, link=None):
         """`skip` is an extension used by UpConcat: returns cat((up(x), skip), dim=1) written in place.
         `link`: ops.SkipLink of this skip connection (Unet passes it; see _ops.SkipLink)."""
@@ -382,6 +393,23 @@ class ResBlock(nn.Module):
                 or float(self.dropout.p) == 0.0):
             return None
         return (n, ops.cpad(self.out_channels) if self._pad else self.out_channels, float(self.dropout.p))
+
+    def _pack_specs(self):
+        """The packed weight forms ops.ResBlockFn asks for in a training pass (same tuples: ops.prepack keys on them)."""
+        w1, w2 = self.conv1.weight, self.conv2.weight
+        cout, cin = w1.shape[0], w1.shape[1]
+        cout_seg = cout if self._pad else 0
+        cin_seg = (cin // self._in_segs) if self._pad else 0
+        specs = [(w1, N.ROLE_CONV_FWD, self.stride, cout_seg, cin_seg), (w1, N.ROLE_CONV_DGRAD, self.stride, cout_seg, cin_seg),
+                 (w2, N.ROLE_CONV_FWD, 1, cout_seg, cout_seg), (w2, N.ROLE_CONV_DGRAD, 1, cout_seg, cout_seg)]
+        biases = [self.conv1.bias, self.conv2.bias]
+        if self.uses_skip_conv:
+            ws = self.skip_conv.weight
+            specs += [(ws, N.ROLE_CONV_FWD, self.stride, cout_seg, cin_seg), (ws, N.ROLE_CONV_DGRAD, self.stride, cout_seg, cin_seg)]
+            biases.append(self.skip_conv.bias)
+        if cout_seg:
+            specs += [(b, N.ROLE_BIAS, 1, cout_seg, 0) for b in biases if b is not None]
+        return specs
 
     def forward(self, x, in_link=None, out_link=None):
         """in_link / out_link: ops.SkipLink objects Unet passes to the pooling block / the last encoder block of a
@@ -595,6 +623,20 @@ class Unet(nn.Module):
             return ops.ConvFn.apply(x, self.fc.weight, self.fc.bias, 1, x.dtype, torch.float32, self._pad, False)
         return self.fc(x)
 
+    def _prepack(self):
+        """One packing pass for the whole model in front of a training step (ops.prepack): every block of the linked
+        native chain, the stem and the head."""
+        sd = self._storage_dtype()
+        cs = self.conv.weight.shape[0] if self._pad else 0
+        specs = [(self.conv.weight, N.ROLE_CONV_FWD, 1, cs, 0)]
+        if cs and self.conv.bias is not None:
+            specs.append((self.conv.bias, N.ROLE_BIAS, 1, cs, 0))
+        for blk in self._native_chain() or []:
+            specs += blk._pack_specs()
+        ci = self.fc.weight.shape[1] if self._pad else 0
+        specs += [(self.fc.weight, N.ROLE_CONV_FWD, 1, 0, ci), (self.fc.weight, N.ROLE_CONV_DGRAD, 1, 0, ci)]
+        ops.prepack(specs, sd)
+
     def _set_bn_pad(self, pad):
         """BatchNorm nets are native in inference mode only, so their channel padding is decided per forward."""
         if pad != self._pad:
@@ -605,9 +647,11 @@ class Unet(nn.Module):
     def forward(self, x):
         if self._bn_blocks is not None:
             self._set_bn_pad(self._pad_bn and x.is_cuda and _bn_on_device(self))
+        linked = self._linked and x.is_cuda
+        if linked and torch.is_grad_enabled() and self._storage_dtype() != torch.float32:
+            self._prepack()
         x = self._stem(x)
         skips, links = [], []
-        linked = self._linked and x.is_cuda
         if linked and self.training:
             # every Dropout3d factor of the pass from one launch (ops.prefill_dropout), in the blocks' execution order
             order = []

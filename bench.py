@@ -326,7 +326,7 @@ def main():
     gc.freeze()
     probe = None
     if not args.no_probe and dtype != torch.float32:
-        probe = ops.Probe(cin=args.features, cout=args.features, k=3, stride=1, extent=dims)
+        probe = ops.Probe(n=args.batch, cin=args.features, cout=args.features, extent=dims)
         if not use_graph:
             ops.set_probe(probe)
     if not use_graph:
@@ -434,7 +434,9 @@ def main():
                     traffic = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))[key]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
-            out["roofline"] = {"kernel": "conv3d k3 s1 %d->%d on %dx%s (fwd + dgrad launches)" %
+            out["roofline"] = {"kernel": "conv3d k3 s1 %d->%d on %dx%s: every launch of the step's eager twin (forward with "
+                                         "fused InstanceNorm statistics, input gradient plain and with fused backward "
+                                         "sums), HIP events recorded by the library around the kernel alone" %
                                          (c, c, args.batch, shape_txt),
                                "bound": "mfma", "achieved": mf / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                                "frac": mf / MFMA_BF16_PEAK, "traffic": traffic, "launches": n_launch,

@@ -85,7 +85,7 @@ int ru3d_pack_weight(const float* src, void* dst, int cout, int cin, int k, int 
  * zero rows / columns to the next multiple of 32 (cin_seg = 30 for cin = 60 is the decoder's concat input
  * 30 | 30 -> 32 | 32, network.py:350).  dst is then ru3d_packed_weight_bytes(padded cout, padded cin, ...) long.
  * Role RU3D_ROLE_BIAS pads a bias vector the same way (src fp32 [cout], dst fp32 [padded cout]; k = 1). */
-#define RU3D_PACK_MAX 12
+#define RU3D_PACK_MAX 40
 typedef struct ru3d_pack_item {
     const float* src; /* fp32 weight, reference layout                  */
     void* dst;        /* packed output, ru3d_packed_weight_bytes() long  */
@@ -117,6 +117,17 @@ size_t ru3d_conv3d_fwd_in_workspace_bytes(const ru3d_tensor* x, const ru3d_tenso
 int ru3d_conv3d_fwd_in(const ru3d_tensor* x, const void* w_packed, const float* bias, const ru3d_tensor* y, int k,
                        int stride, int dtype, const float* drop_scale, float* mean, float* scale, void* ws,
                        size_t ws_bytes, float eps, void* stream);
+/* conv + InstanceNorm statistics + apply + LeakyReLU behind one entry point - a ResBlock's conv -> dropout -> norm ->
+ * nonlin chain (reference network.py:405-416) and, with `res`, its tail lrelu(IN(conv2(x)) + skip):
+ *     y = conv(x) + bias;  (mean, scale) as ru3d_conv3d_fwd_in;  out = lrelu((y - mean) * scale (+ res))
+ * y is kept (the backward reads it).  On small levels (<= 4096 voxels per sample, 16-bit storage) the statistics, their
+ * finalize and the apply are one whole-instance kernel that also sums the conv's split-K slices; elsewhere the call is
+ * ru3d_conv3d_fwd_in + ru3d_in_lrelu_fwd.  Workspace: ru3d_conv3d_fwd_in_lrelu_workspace_bytes. */
+size_t ru3d_conv3d_fwd_in_lrelu_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* y, int k, int stride, int dtype);
+int ru3d_conv3d_fwd_in_lrelu(const ru3d_tensor* x, const void* w_packed, const float* bias, const ru3d_tensor* y, int k,
+                             int stride, int dtype, const float* drop_scale, float* mean, float* scale,
+                             const ru3d_tensor* res, const ru3d_tensor* out, float slope, void* ws, size_t ws_bytes,
+                             float eps, void* stream);
 /* input gradient of the same conv: dx = conv_dgrad(dy) (+ res).  w_packed made with ROLE_CONV_DGRAD. */
 int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* res,
                       const ru3d_tensor* dx, int k, int stride, int dtype, void* ws, size_t ws_bytes,
@@ -150,13 +161,6 @@ int ru3d_conv3d_s2_dgrad_pair(const ru3d_tensor* dy, const void* w3_packed, cons
 size_t ru3d_conv3d_wgrad_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* dy, int k, int stride, int dtype);
 int ru3d_conv3d_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, float* dw, void* ws, size_t ws_bytes,
                       int k, int stride, int dtype, void* stream);
-
-/* Several weight gradients whose slab sums go out as ONE launch: between `begin` and `flush` (same host thread, same
- * stream, same dtype) every ru3d_conv3d_wgrad / ru3d_convtranspose3d_k3s2p1_wgrad call runs its main kernel at once but
- * only records its fixed-order slab sum; `flush` issues the recorded sums together.  The caller must give every
- * deferred call its OWN workspace (the slabs live there until the flush) and must not read dw before the flush. */
-int ru3d_wgrad_defer_begin(int dtype);
-int ru3d_wgrad_defer_flush(int dtype, void* stream);
 
 /* nn.ConvTranspose3d(k3,s2,p1) followed by ConstantPad3d((0,1,0,1,0,1),0) (network.py:312-314):
  * y has extents 2*x.{d,h,w}; its far planes are written as exact zeros (no bias there). */
@@ -407,6 +411,12 @@ int ru3d_comm_available(void);
 int ru3d_comm_destroy(void* comm);
 /* Compute units the persistent conv kernels may occupy (their grids are sized from it); 0 restores the device's count.
  * A data-parallel rank leaves a few CUs to RCCL's reduction kernels on the side stream. */
+/* Kernel probe (bench.py's `roofline` object): between begin and end the library records a HIP-event pair on the launch
+ * stream around the main kernel of every 3x3x3 stride-1 conv launch (forward or input gradient, any entry point) whose
+ * output grid is n x d x h x w with cin -> cout channels; `end` waits for them and returns their number and the sum of
+ * their durations.  Launches made while the stream is being captured into a graph are skipped. */
+int ru3d_probe_begin(int n, int d, int h, int w, int cin, int cout);
+int ru3d_probe_end(int* launches, double* total_ms);
 int ru3d_set_cu_budget(int cus);
 int ru3d_get_cu_budget(void);
 /* dst[i] = (dst_dtype)(src[i] * scale) on flat 16-byte-aligned device arrays, f32 <-> bf16: the copy-in / copy-out
