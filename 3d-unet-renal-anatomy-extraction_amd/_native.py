@@ -23,7 +23,8 @@ MAX_CLASSES = 8
 class Tensor(ctypes.Structure):
     """struct ru3d_tensor"""
     _fields_ = [("ptr", ctypes.c_void_p), ("n", ctypes.c_int32), ("d", ctypes.c_int32), ("h", ctypes.c_int32),
-                ("w", ctypes.c_int32), ("c", ctypes.c_int32), ("ld", ctypes.c_int32)]
+                ("w", ctypes.c_int32), ("c", ctypes.c_int32), ("ld", ctypes.c_int32), ("cseg", ctypes.c_int32),
+                ("seg_stride", ctypes.c_int64)]
 
 
 class PackItem(ctypes.Structure):
@@ -62,6 +63,7 @@ SIGNATURES = {
     "ru3d_conv3d_fwd_in": (_i, [_P, _vp, _vp, _P, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _f, _vp]),
     "ru3d_conv3d_fwd_in_lrelu_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),
     "ru3d_conv3d_fwd_in_lrelu": (_i, [_P, _vp, _vp, _P, _i, _i, _i, _vp, _vp, _vp, _P, _P, _f, _vp, _sz, _f, _vp]),
+    "ru3d_planar_concat_supported": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "ru3d_conv3d_dgrad": (_i, [_P, _vp, _P, _P, _i, _i, _i, _vp, _sz, _vp]),
     "ru3d_conv3d_s2_pair_fwd_in_supported": (_i, [_P, _P, _P, _i]),
     "ru3d_conv3d_s2_pair_fwd_in_workspace_bytes": (_sz, [_P, _P, _i]),
@@ -234,12 +236,38 @@ def to_ndhwc(t):
     return t.contiguous(memory_format=torch.channels_last_3d)
 
 
+class Split:
+    """torch.cat((a, b), dim=1) held as two PLANES of one buffer (ru3d_tensor's split layout): `t` is the NDHWC tensor
+    [2N, C/2, D, H, W] whose first N samples are `a` and last N samples `b`.  Quacks like the [N, C, D, H, W] concat for
+    the wrappers in _ops (shape / dtype / device) and describes itself to the C ABI with cseg = C/2."""
+
+    def __init__(self, t):
+        n2, c, d, h, w = t.shape
+        if n2 % 2 or not is_ndhwc(t) or not t.is_contiguous(memory_format=torch.channels_last_3d):
+            raise Ru3dError("ru3d: a split concat must be a dense NDHWC tensor [2N, C/2, D, H, W]")
+        self.t = t
+        self.shape = torch.Size((n2 // 2, 2 * c, d, h, w))
+        self.dtype = t.dtype
+        self.device = t.device
+        self.is_cuda = t.is_cuda
+
+    def element_size(self):
+        return self.t.element_size()
+
+    def desc(self):
+        n, c, d, h, w = self.shape
+        _tls.device = self.t.device
+        return Tensor(self.t.data_ptr(), n, d, h, w, c, c // 2, c // 2, n * d * h * w * (c // 2))
+
+
 _GEOM = {}
 
 
 def desc(t):
     """ru3d_tensor descriptor of an NDHWC-strided [N,C,D,H,W] torch tensor.  The (shape, strides) -> geometry
     part is memoised: the same few dozen layouts recur every step."""
+    if isinstance(t, Split):
+        return t.desc()
     if not t.is_cuda:
         require_device(t)
     _tls.device = t.device

@@ -421,15 +421,16 @@ def conv_s2_pair_fwd_in(x, pw3, b3, pw1, b1, cout, drop_scale=None):
     return y3, mean, scale, y1
 
 
-def conv_s1_dgrad_pair(dy, pw3, dy2, pw1, in_shape):
+def conv_s1_dgrad_pair(dy, pw3, dy2, pw1, in_shape, planar=False):
     """Input gradient of a decoder ResBlock's conv1 (k3 s1) and skip_conv (k1 s1) in one launch; None when the shapes
-    have no fused kernel."""
+    have no fused kernel.  planar: the gradient of a split concat input - returned as the [2N, C/2, D, H, W] tensor of
+    its two planes (N.Split)."""
     n, cin, d, h, w = in_shape
     code = N.dtype_code(dy.dtype)
     if code == N.F32:
         return None
-    dx = N.new_act(n, cin, d, h, w, dy.dtype, dy.device)
-    ddy, ddy2, ddx = desc(dy), desc(dy2), desc(dx)
+    dx = N.new_act(2 * n, cin // 2, d, h, w, dy.dtype, dy.device) if planar else N.new_act(n, cin, d, h, w, dy.dtype, dy.device)
+    ddy, ddy2, ddx = desc(dy), desc(dy2), desc(N.Split(dx) if planar else dx)
     if not N.lib.ru3d_conv3d_s1_dgrad_pair_supported(ref(ddy), ref(ddy2), ref(ddx), code):
         return None
     check(N.lib.ru3d_conv3d_s1_dgrad_pair(ref(ddy), ptr(pw3), ref(ddy2), ptr(pw1), ref(ddx), code, stream()),
@@ -849,14 +850,28 @@ class SkipLink:
         gradient kernel adds it as its residual operand.  UpFn's backward always runs before the pooling block's (the
         decoder level sits above everything the pooling block feeds)."""
 
-    def __init__(self, up_channels):
+    def __init__(self, up_channels, dec_channels=0):
         self.up_channels = up_channels      # channels (padded when the net is padded) of the up-sampled half
+        self.dec_channels = dec_channels    # output channels of the decoder block that consumes the concat
         self.buf = None
         self.grad = None
+        self.planar = False                 # the concat is two planes of one buffer (N.Split), not interleaved channels
 
     def skip_view(self, n, c, d, h, w, dtype, device):
+        self.planar = False
         self.buf = N.new_act(n, self.up_channels + c, d, h, w, dtype, device)
         return self.buf[:, self.up_channels:]
+
+    def planar_view(self, n, c, d, h, w, dtype, device):
+        """Full-resolution level (32 + 32 channels of 16 bits: interleaved, the halves would share every 128-byte line):
+        the concat as two planes [up | skip] of one buffer when every kernel of the decoder block takes that
+        (ru3d_planar_concat_supported); the skip plane, or None."""
+        if (c != self.up_channels or dtype == torch.float32 or not self.dec_channels
+                or not N.lib.ru3d_planar_concat_supported(n, d, h, w, c, self.dec_channels, N.dtype_code(dtype))):
+            return None
+        self.planar = True
+        self.buf = N.new_act(2 * n, c, d, h, w, dtype, device)
+        return self.buf[n:]
 
 
 # --------------------------------------------------------------------------- autograd: plain conv (stem / head / skip)
@@ -928,11 +943,15 @@ class ResBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, ws, bs, stride, drop_scale, pad=0, checkpoint=False, in_link=None,
-                out_link=None):
+                out_link=None, planar=False):
         """in_link: SkipLink whose parked gradient this block adds to its input gradient (pooling block);
-        out_link: SkipLink into whose concat buffer the block writes its output (last encoder block of a level)."""
+        out_link: SkipLink into whose concat buffer the block writes its output (last encoder block of a level);
+        planar: x is a split concat - the [2N, C/2, D, H, W] tensor of its two planes (N.Split, UpFn made it)."""
         sd = x.dtype
         x = N.to_ndhwc(x)
+        xt = x                      # the tensor autograd sees
+        if planar:
+            x = N.Split(x)
         cout, cin = w1.shape[0], w1.shape[1]
         cin_seg = seg_of(cin, x.shape[1], int(pad)) if pad else 0      # pad = number of input segments
         cout_seg = cout if pad else 0
@@ -973,6 +992,8 @@ class ResBlockFn(torch.autograd.Function):
         zout = None
         if out_link is not None and cout_p * a1.element_size() >= 128:
             zout = out_link.skip_view(n_, cout_p, d_, h_, w_, sd, x.device)
+        elif out_link is not None:
+            zout = out_link.planar_view(n_, cout_p, d_, h_, w_, sd, x.device)      # None: the copy path
         z = None
         # decoder block on the large levels: skip conv + IN apply + sum + LeakyReLU in one pass, the skip never stored
         # (no link buffer then: decoder outputs are not skips); the shapes are skip1x1_fused_eligible's
@@ -993,11 +1014,12 @@ class ResBlockFn(torch.autograd.Function):
             y2, mean2, scale2, z = conv_fwd_in_act(a1, pw2, b2, cout_p, 3, 1, res=skip, out=zout)
         bwd = packs[nfwd:nw] + [None] * 3
         if checkpoint and train:
-            ctx.save_for_backward(x, None, None, None, z, mean1, scale1, mean2, scale2, bwd[0], bwd[1], bwd[2],
+            ctx.save_for_backward(xt, None, None, None, z, mean1, scale1, mean2, scale2, bwd[0], bwd[1], bwd[2],
                                   pw1, pw2, b1, b2)
         else:
-            ctx.save_for_backward(x, y1, a1, y2, z, mean1, scale1, mean2, scale2, bwd[0], bwd[1], bwd[2],
+            ctx.save_for_backward(xt, y1, a1, y2, z, mean1, scale1, mean2, scale2, bwd[0], bwd[1], bwd[2],
                                   None, None, None, None)
+        ctx.planar = bool(planar)
         ctx.dims = (cout, cin, cout_seg, cin_seg)
         ctx.stride = stride
         plain = not (cout_seg or cin_seg)
@@ -1018,6 +1040,8 @@ class ResBlockFn(torch.autograd.Function):
         dev = x.device
         stride = ctx.stride
         gz = as_grad(gz, sd)
+        if ctx.planar:
+            x = N.Split(x)
         if y1 is None:      # checkpointed: the same kernels on the same inputs give the same bits
             y1 = conv_fwd(x, pw1, b1, cout_p, 3, stride)
             a1 = in_lrelu_fwd(y1, mean1, scale1)
@@ -1035,7 +1059,8 @@ class ResBlockFn(torch.autograd.Function):
         stride = ctx.stride
         gws = gbs = None
         nvox = dy2.shape[0] * dy2.shape[2] * dy2.shape[3] * dy2.shape[4]
-        with _OnSide(dev, nvox, (a1, dy2, x, gpre)):
+        xk = x.t if ctx.planar else x
+        with _OnSide(dev, nvox, (a1, dy2, xk, gpre)):
             gw2 = unpad_wgrad(conv_wgrad(a1, dy2, 3, 1, key=ctx.wkeys[1]), cout, cout, cout_seg, cout_seg)
             if ctx.has_skip_conv:
                 gws = unpad_wgrad(conv_wgrad(x, gpre, 1, stride, key=ctx.wkeys[2]), cout, cin, cout_seg, cin_seg)
@@ -1045,7 +1070,7 @@ class ResBlockFn(torch.autograd.Function):
         # sums are taken in the conv's epilogue
         dy1 = conv_dgrad_in_bwd(dy2, pw2d, a1, mean1, scale1)
         del dy2, a1, y1
-        with _OnSide(dev, nvox, (x, dy1)):
+        with _OnSide(dev, nvox, (xk, dy1)):
             gw1 = unpad_wgrad(conv_wgrad(x, dy1, 3, stride, key=ctx.wkeys[0]), cout, cin, cout_seg, cin_seg)
         gb1 = None
         gx = None
@@ -1058,14 +1083,16 @@ class ResBlockFn(torch.autograd.Function):
                 if stride == 2:     # both stride-2 input gradients (+ the parked concat share) in one launch
                     gx = conv_s2_dgrad_pair(dy1, pw1d, gpre, pwsd, tuple(x.shape), res=parked)
                 elif parked is None:
-                    gx = conv_s1_dgrad_pair(dy1, pw1d, gpre, pwsd, tuple(x.shape))
+                    gx = conv_s1_dgrad_pair(dy1, pw1d, gpre, pwsd, tuple(x.shape), planar=ctx.planar)
+                if gx is None and ctx.planar:
+                    raise N.Ru3dError("ResBlock: the split concat input has no fused input-gradient kernel for this shape")
                 if gx is None:
                     gx0 = conv_dgrad(gpre, pwsd, tuple(x.shape), 1, stride, res=parked)
                     gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gx0)
         elif need_gx:
             gx = conv_dgrad(dy1, pw1d, tuple(x.shape), 3, stride, res=gpre)
         _join(dev, gw1, gw2, gws, gbs)
-        return gx, gw1, gb1, gw2, gb2, gws, gbs, None, None, None, None, None, None
+        return gx, gw1, gb1, gw2, gb2, gws, gbs, None, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------- autograd: ConvTrans3D (+ concat)
@@ -1101,16 +1128,27 @@ class UpFn(torch.autograd.Function):
             cs = skip.shape[1]
             if tuple(skip.shape[2:]) != (d, h, w) or skip.shape[0] != n:
                 raise N.Ru3dError("UpConcat: skip %s does not match up-sampled %s" % (tuple(skip.shape), tuple(y.shape)))
-            in_place = (link is not None and link.buf is not None and link.up_channels == cout_p
+            planar = (link is not None and link.planar and link.buf is not None and link.up_channels == cout_p == cs
+                      and tuple(link.buf.shape) == (2 * n, cs, d, h, w) and link.buf.dtype == sd
+                      and skip.data_ptr() == link.buf[n:].data_ptr())
+            in_place = (not planar and link is not None and not link.planar and link.buf is not None
+                        and link.up_channels == cout_p
                         and tuple(link.buf.shape) == (n, cout_p + cs, d, h, w) and link.buf.dtype == sd
                         and skip.data_ptr() == link.buf[:, cout_p:].data_ptr())
-            buf = link.buf if in_place else N.new_act(n, cout_p + cs, d, h, w, sd, x.device)
-            u = buf[:, :cout_p]
-            in_lrelu_fwd(y, mean, scale, out=u)
-            if not in_place:
-                copy_channels(skip, buf[:, cout_p:])
+            if planar:
+                # the concat as two planes [u | skip] of one buffer: the encoder wrote the skip plane, u is a dense tensor
+                # of its own; the decoder block takes the pair as a split tensor (N.Split)
+                buf = link.buf
+                in_lrelu_fwd(y, mean, scale, out=buf[:n])
+            else:
+                buf = link.buf if in_place else N.new_act(n, cout_p + cs, d, h, w, sd, x.device)
+                u = buf[:, :cout_p]
+                in_lrelu_fwd(y, mean, scale, out=u)
+                if not in_place:
+                    copy_channels(skip, buf[:, cout_p:])
             if link is not None:
                 link.buf = None          # the autograd graph owns the buffer from here on
+                link.planar_out = planar
             out = buf
         else:
             u = in_lrelu_fwd(y, mean, scale)
@@ -1118,6 +1156,7 @@ class UpFn(torch.autograd.Function):
         ctx.save_for_backward(x, y, out, mean, scale, packs[1] if ctx.needs_input_grad[0] else None)
         ctx.dims = (cout, cin, cout_seg, cin_seg)
         ctx.has_skip = skip is not None
+        ctx.planar = bool(skip is not None and link is not None and getattr(link, "planar_out", False))
         ctx.wkey = wt.data_ptr() if not (cout_seg or cin_seg) else None
         ctx.link = link if (link is not None and getattr(link, "fused_grad", False)) else None
         return out
@@ -1129,9 +1168,13 @@ class UpFn(torch.autograd.Function):
         cout_p = padded_dim(cout, cout_seg)
         sd = x.dtype
         g = as_grad(g, sd)
-        u = out[:, :cout_p] if ctx.has_skip else out
-        gu = g[:, :cout_p] if ctx.has_skip else g
-        gskip = g[:, cout_p:] if ctx.has_skip else None
+        if ctx.planar:              # planes [u | skip] of one buffer: dense halves
+            n = out.shape[0] // 2
+            u, gu, gskip = out[:n], g[:n], g[n:]
+        else:
+            u = out[:, :cout_p] if ctx.has_skip else out
+            gu = g[:, :cout_p] if ctx.has_skip else g
+            gskip = g[:, cout_p:] if ctx.has_skip else None
         dy, _ = in_lrelu_bwd(gu, u, y, mean, scale, zero_far=True)
         nvox = x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4]
         with _OnSide(x.device, nvox, (x, dy)):

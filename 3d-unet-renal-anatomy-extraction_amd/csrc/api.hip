@@ -203,6 +203,12 @@ static int run_conv(const ru3d_tensor* x, const void* w, const float* bias, cons
     g.ldr = res ? res->ld : 0;
     g.k = k; g.stride = stride; g.pad = k / 2;
     g.transposed = transposed; g.zero_far = zero_far; g.flip = flip;
+    g.x_cseg = x->cseg; g.x_segstride = x->seg_stride; g.y_cseg = y->cseg; g.y_segstride = y->seg_stride;
+    if (g.x_cseg || g.y_cseg) {      // the planar concat: only the MFMA conv kernels of a decoder ResBlock take it
+        if (!(mfma_conv_eligible(g.Cin, g.Cout, k, dtype, y_dtype) && mfma_conv_geometry_ok(g)))
+            return ru3d_fail(-1, "conv3d: no kernel takes a split tensor for this shape / dtype");
+        return conv_mfma_launch(x->ptr, w, bias, res ? res->ptr : nullptr, y->ptr, g, st, nullptr, ws, ws_bytes);
+    }
     if (stem_fwd_eligible(g, dtype, y_dtype, res)) return stem_fwd_launch(x->ptr, w, bias, y->ptr, g, dtype, st);
     if (head_fwd_eligible(g, dtype, res)) return head_fwd_launch(x->ptr, w, bias, y->ptr, g, dtype, y_dtype, st);
     if (!bias && head_dgrad_eligible(g, dtype, y_dtype, res)) return head_dgrad_launch(x->ptr, w, y->ptr, g, dtype, st);
@@ -226,7 +232,7 @@ static bool res_ok(const ru3d_tensor* res, const ru3d_tensor* y) {
 // the input gradient of a stride-1 conv (call it with (dy, dx)).
 extern "C" size_t ru3d_conv3d_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* y, int k, int stride, int dtype) {
     RU3D_FWD_F16(dtype, ru3d_conv3d_workspace_bytes_f16(x, y, k, stride, dtype));
-    if (!tensor_ok(x) || !tensor_ok(y) || dtype != RU3D_BF16 || k != 3 || stride != 1) return 0;
+    if (!tensor_ok_split(x) || !tensor_ok(y) || dtype != RU3D_BF16 || k != 3 || stride != 1) return 0;
     if (!mfma_conv_eligible(x->c, y->c, k, dtype, dtype)) return 0;
     ConvGeom g;
     g.N = x->n;
@@ -244,7 +250,7 @@ extern "C" int ru3d_conv3d_fwd(const ru3d_tensor* x, const void* w_packed, const
                                size_t ws_bytes, void* stream) {
     RU3D_FWD_F16(dtype, ru3d_conv3d_fwd_f16(x, w_packed, bias, res, y, k, stride, dtype, y_dtype, ws, ws_bytes, stream));
     Ru3dDeviceGuard dev_guard(stream);
-    RU3D_REQUIRE(tensor_ok(x) && tensor_ok(y) && w_packed, "conv3d_fwd: bad tensor/weight");
+    RU3D_REQUIRE(tensor_ok_split(x) && tensor_ok(y) && w_packed, "conv3d_fwd: bad tensor/weight");
     RU3D_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "conv3d_fwd: k=%d stride=%d unsupported", k, stride);
     RU3D_REQUIRE(dtype_ok(dtype) && dtype_ok(y_dtype) && !(dtype == RU3D_F32 && y_dtype == RU3D_BF16),
                  "conv3d_fwd: bad dtypes %d -> %d", dtype, y_dtype);
@@ -265,6 +271,7 @@ static ConvGeom fwd_geom(const ru3d_tensor* x, const ru3d_tensor* y, int k, int 
     g.ldr = 0;
     g.k = k; g.stride = stride; g.pad = k / 2;
     g.transposed = 0; g.zero_far = 0; g.flip = 0;
+    g.x_cseg = x->cseg; g.x_segstride = x->seg_stride; g.y_cseg = y->cseg; g.y_segstride = y->seg_stride;
     return g;
 }
 
@@ -276,7 +283,7 @@ static bool fwd_in_fused(const ru3d_tensor* x, const ru3d_tensor* y, int k, int 
 extern "C" size_t ru3d_conv3d_fwd_in_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* y, int k, int stride,
                                                      int dtype) {
     RU3D_FWD_F16(dtype, ru3d_conv3d_fwd_in_workspace_bytes_f16(x, y, k, stride, dtype));
-    if (!tensor_ok(x) || !tensor_ok(y)) return 0;
+    if (!tensor_ok_split(x) || !tensor_ok(y)) return 0;
     size_t need = ru3d_reduce_workspace_bytes(y);
     if (fwd_in_fused(x, y, k, stride, dtype)) {
         const size_t slab = mfma_conv_stats_slab_bytes(fwd_geom(x, y, k, stride));
@@ -292,7 +299,7 @@ extern "C" int ru3d_conv3d_fwd_in(const ru3d_tensor* x, const void* w_packed, co
                                   void* ws, size_t ws_bytes, float eps, void* stream) {
     RU3D_FWD_F16(dtype, ru3d_conv3d_fwd_in_f16(x, w_packed, bias, y, k, stride, dtype, drop_scale, mean, scale, ws, ws_bytes, eps, stream));
     Ru3dDeviceGuard dev_guard(stream);
-    RU3D_REQUIRE(tensor_ok(x) && tensor_ok(y) && w_packed && mean && scale && ws, "conv3d_fwd_in: bad argument");
+    RU3D_REQUIRE(tensor_ok_split(x) && tensor_ok(y) && w_packed && mean && scale && ws, "conv3d_fwd_in: bad argument");
     RU3D_REQUIRE(ws_bytes >= ru3d_conv3d_fwd_in_workspace_bytes(x, y, k, stride, dtype), "conv3d_fwd_in: workspace too small");
     if (fwd_in_fused(x, y, k, stride, dtype)) {
         RU3D_REQUIRE(x->n == y->n && y->d == x->d && y->h == x->h && y->w == x->w, "conv3d_fwd_in: extents mismatch");
@@ -333,7 +340,7 @@ extern "C" int ru3d_conv3d_fwd_in_lrelu(const ru3d_tensor* x, const void* w_pack
                                         size_t ws_bytes, float eps, void* stream) {
     RU3D_FWD_F16(dtype, ru3d_conv3d_fwd_in_lrelu_f16(x, w_packed, bias, y, k, stride, dtype, drop_scale, mean, scale, res, out, slope, ws, ws_bytes, eps, stream));
     Ru3dDeviceGuard dev_guard(stream);
-    RU3D_REQUIRE(tensor_ok(x) && tensor_ok(y) && tensor_ok(out) && w_packed && mean && scale && ws,
+    RU3D_REQUIRE(tensor_ok_split(x) && tensor_ok(y) && tensor_ok(out) && w_packed && mean && scale && ws,
                  "conv3d_fwd_in_lrelu: bad argument");
     RU3D_REQUIRE(res_ok(res, y) && res_ok(out, y), "conv3d_fwd_in_lrelu: res / out do not have the shape of y");
     const int small = (small_conv_path(x, y, k, stride, dtype) && x->n == y->n && y->d == x->d && y->h == x->h &&
@@ -351,6 +358,34 @@ extern "C" int ru3d_conv3d_fwd_in_lrelu(const ru3d_tensor* x, const void* w_pack
     int rc = ru3d_conv3d_fwd_in(x, w_packed, bias, y, k, stride, dtype, drop_scale, mean, scale, ws, ws_bytes, eps, stream);
     if (rc) return rc;
     return ru3d_in_lrelu_fwd(y, mean, scale, res, out, slope, dtype, stream);
+}
+
+// ---- can a decoder ResBlock take cat((up, skip)) as a split tensor through all of its kernels? (see ru3d_tensor)
+extern "C" int ru3d_planar_concat_supported(int n, int d, int h, int w, int cseg, int cout, int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_planar_concat_supported_f16(n, d, h, w, cseg, cout, dtype));
+    static const int mode = getenv("RU3D_PLANAR_CONCAT") ? atoi(getenv("RU3D_PLANAR_CONCAT")) : 1;
+    if (!mode || dtype != RU3D_BF16 || n <= 0 || d <= 0 || h <= 0 || w <= 0 || cseg != 32 || cout != 32) return 0;
+    const int64_t V = (int64_t)d * h * w;
+    // byte offsets of the sliding kernel's staging: plane distance + one sample below 2^31
+    if (((int64_t)n * V + V) * cseg * 2 >= (1ll << 31)) return 0;
+    SlidePlan sp;
+    if (!slide64_conv_plan(n, d, h, w, 2 * cseg, cout, &sp)) return 0;                 // conv1 forward (split input)
+    ConvGeom gd;                                                                       // its input-gradient pair (split output)
+    gd.N = n; gd.Di = gd.Do = d; gd.Hi = gd.Ho = h; gd.Wi = gd.Wo = w; gd.Cin = cout; gd.Cout = 2 * cseg;
+    gd.ldx = cout; gd.ldy = cseg; gd.CoutPad = 2 * cseg; gd.ldr = 0; gd.k = 3; gd.stride = 1; gd.pad = 1;
+    gd.transposed = 0; gd.zero_far = 0; gd.flip = 1;
+    static const int pair_mode = getenv("RU3D_DGRAD_PAIR") ? atoi(getenv("RU3D_DGRAD_PAIR")) : 1;
+    if (!pair_mode || !mfma_conv_eligible(gd.Cin, gd.Cout, 3, dtype, dtype) || !mfma_conv_can_fuse_partner(gd)) return 0;
+    WgradGeom gw;                                                                      // conv1's weight gradient (split x)
+    gw.N = n; gw.Di = gw.Do = d; gw.Hi = gw.Ho = h; gw.Wi = gw.Wo = w; gw.Cin = 2 * cseg; gw.Cout = cout;
+    gw.ldx = cseg; gw.lddy = cout; gw.k = 3; gw.taps = 27; gw.stride = 1; gw.pad = 1;
+    gw.s_o = (int64_t)gw.Cin * 27; gw.s_i = 27; gw.chunk_len = 0;
+    WgradSlidePlan wp;
+    if (!wgrad_slide_plan(gw, &wp)) return 0;
+    // the fused tail (skip conv + InstanceNorm apply): skip1x1_fused_eligible's shape conditions
+    static const int skip_mode = getenv("RU3D_FUSED_SKIP") ? atoi(getenv("RU3D_FUSED_SKIP")) : 1;
+    if (!skip_mode || (V % 16) != 0 || V * n < 65536) return 0;
+    return 1;
 }
 
 extern "C" int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* res,
@@ -377,7 +412,8 @@ static ConvGeom dgrad_s1_geom(const ru3d_tensor* dy, const ru3d_tensor* da, int 
 extern "C" int ru3d_conv3d_s1_dgrad_pair_supported(const ru3d_tensor* dy, const ru3d_tensor* dy2, const ru3d_tensor* dx, int dtype) {
     RU3D_FWD_F16(dtype, ru3d_conv3d_s1_dgrad_pair_supported_f16(dy, dy2, dx, dtype));
     static const int mode = getenv("RU3D_DGRAD_PAIR") ? atoi(getenv("RU3D_DGRAD_PAIR")) : 1;
-    if (!mode || dtype != RU3D_BF16 || !tensor_ok(dy) || !tensor_ok(dy2) || !tensor_ok(dx)) return 0;
+    if (!mode || dtype != RU3D_BF16 || !tensor_ok(dy) || !tensor_ok(dy2) || !tensor_ok_split(dx)) return 0;
+    if (dx->cseg && (dx->cseg != 32 || dx->c != 64)) return 0;      // split output: two 32-channel slices, one per grid row
     if (dy2->n != dy->n || dy2->d != dy->d || dy2->h != dy->h || dy2->w != dy->w || dy2->c != dy->c) return 0;
     if (dx->n != dy->n || dx->d != dy->d || dx->h != dy->h || dx->w != dy->w) return 0;
     if ((dy->ld % 8) || (dy2->ld % 8) || (dx->ld % 8)) return 0;
@@ -580,11 +616,12 @@ static WgradGeom make_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, int k, 
     g.s_o = (int64_t)x->c * g.taps;
     g.s_i = g.taps;
     g.chunk_len = 0;
+    g.x_cseg = x->cseg; g.x_segstride = x->seg_stride;
     return g;
 }
 
 static bool wgrad_shapes_ok(const ru3d_tensor* x, const ru3d_tensor* dy, int k, int stride) {
-    return tensor_ok(x) && tensor_ok(dy) && x->n == dy->n && dy->d == conv_out(x->d, k, stride) &&
+    return tensor_ok_split(x) && tensor_ok(dy) && x->n == dy->n && dy->d == conv_out(x->d, k, stride) &&
            dy->h == conv_out(x->h, k, stride) && dy->w == conv_out(x->w, k, stride);
 }
 
@@ -593,6 +630,7 @@ extern "C" size_t ru3d_conv3d_wgrad_workspace_bytes(const ru3d_tensor* x, const 
     RU3D_FWD_F16(dtype, ru3d_conv3d_wgrad_workspace_bytes_f16(x, dy, k, stride, dtype));
     if (!wgrad_shapes_ok(x, dy, k, stride)) return 0;
     WgradGeom g = make_wgrad(x, dy, k, stride);
+    if (g.x_cseg) return mfma_wgrad_eligible(g, dtype) ? wgrad_mfma_ws_bytes(g) : 0;
     if (stem_wgrad_eligible(g)) return stem_wgrad_ws_bytes(g);
     if (head_wgrad_eligible(g, dtype)) return head_wgrad_ws_bytes(g);
     if (mfma_wgrad_eligible(g, dtype)) return wgrad_mfma_ws_bytes(g);
@@ -607,6 +645,10 @@ extern "C" int ru3d_conv3d_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, fl
     RU3D_REQUIRE(wgrad_shapes_ok(x, dy, k, stride), "conv3d_wgrad: x/dy shape mismatch");
     RU3D_REQUIRE(dw && dtype_ok(dtype), "conv3d_wgrad: bad argument");
     WgradGeom g = make_wgrad(x, dy, k, stride);
+    if (g.x_cseg) {      // planar concat: the MFMA kernels only (wgrad_mfma_launch refuses the forms that cannot take it)
+        RU3D_REQUIRE(mfma_wgrad_eligible(g, dtype), "conv3d_wgrad: no kernel takes a split x for this shape / dtype");
+        return wgrad_mfma_launch(x->ptr, dy->ptr, dw, ws, ws_bytes, g, as_stream(stream));
+    }
     if (stem_wgrad_eligible(g)) return stem_wgrad_launch(x->ptr, dy->ptr, dw, ws, ws_bytes, g, dtype, as_stream(stream));
     if (head_wgrad_eligible(g, dtype))
         return head_wgrad_launch(x->ptr, dy->ptr, dw, ws, ws_bytes, g, dtype, as_stream(stream));

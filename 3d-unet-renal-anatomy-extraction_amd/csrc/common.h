@@ -93,7 +93,13 @@ struct Ru3dDeviceGuard {
 static inline int64_t nvox(const ru3d_tensor* t) { return (int64_t)t->n * t->d * t->h * t->w; }
 
 static inline int tensor_ok(const ru3d_tensor* t) {
-    return t && t->ptr && t->n > 0 && t->d > 0 && t->h > 0 && t->w > 0 && t->c > 0 && t->ld >= t->c;
+    return t && t->ptr && t->n > 0 && t->d > 0 && t->h > 0 && t->w > 0 && t->c > 0 && t->ld >= t->c && t->cseg == 0;
+}
+// the few entry points that take the split (planar concat) layout: two or more dense segments of cseg channels
+static inline int tensor_ok_split(const ru3d_tensor* t) {
+    if (t && t->cseg == 0) return tensor_ok(t);
+    return t && t->ptr && t->n > 0 && t->d > 0 && t->h > 0 && t->w > 0 && t->c > 0 && t->cseg > 0 && (t->c % t->cseg) == 0 &&
+           t->ld >= t->cseg && t->seg_stride >= (int64_t)t->n * t->d * t->h * t->w * t->ld;
 }
 
 #define RU3D_REQUIRE(cond, ...)                        \

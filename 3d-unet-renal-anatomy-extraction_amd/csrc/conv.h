@@ -14,6 +14,10 @@ struct ConvGeom {
     int transposed;              // 0 = gather form, 1 = transposed (fractionally strided) form
     int zero_far;                // write exact zeros on the last plane of each output axis
     int flip;                    // read weight tap (taps-1-tap): stride-1 dgrad as a gather conv
+    // split (planar concat) layouts, see ru3d_tensor: 0 = dense.  Only the kernels of a decoder ResBlock on the
+    // full-resolution level take them (conv_slide64 input, conv_slide32 pair output)
+    int x_cseg = 0, y_cseg = 0;
+    int64_t x_segstride = 0, y_segstride = 0;
 };
 
 struct WgradGeom {
@@ -23,6 +27,8 @@ struct WgradGeom {
     int k, taps, stride, pad;
     int64_t s_o, s_i;            // element strides of dw for (cout, cin); tap stride is 1
     int64_t chunk_len;           // positions per chunk (filled by the launcher)
+    int x_cseg = 0;              // split (planar concat) x, see ru3d_tensor: 0 = dense
+    int64_t x_segstride = 0;
 };
 
 // batched weight packing (conv_generic.hip): both packed layouts, up to RU3D_PACK_MAX weights per launch

@@ -1663,6 +1663,15 @@ static int conv_mfma_launch_inner(const void* x, const void* w, const float* bia
                                   int* defer_ks) {
     if (defer_ks) *defer_ks = 0;
     if (!mfma_conv_geometry_ok(g)) return ru3d_fail(-1, "conv_mfma: geometry not supported");
+    if (g.x_cseg || g.y_cseg) {
+        // planar concat (see ru3d_tensor): the decoder block's conv1 on the 64-channel sliding kernel (split input), its
+        // input gradient pair on the 32-channel sliding kernel (split output: one plane per 32-channel slice)
+        SlidePlan sp;
+        const bool in_ok = g.x_cseg && !g.y_cseg && g.k == 3 && g.stride == 1 && !g.transposed &&
+                           slide64_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp);
+        const bool out_ok = g.y_cseg && !g.x_cseg && x2 && mfma_conv_can_fuse_partner(g);
+        if (!in_ok && !out_ok) return ru3d_fail(-1, "conv_mfma: no kernel takes this split tensor");
+    }
     if (x2 && !mfma_conv_can_fuse_partner(g)) return ru3d_fail(-1, "conv_mfma: no fused 1x1 partner for this shape");
     if ((g.ldx % 8) || (g.ldy % 4) || (res && (g.ldr % 4)) || !aligned_to(x, 16) || !aligned_to(y, 8) ||
         (res && !aligned_to(res, 8)) || (bias && !aligned_to(bias, 16)) || !aligned_to(w, 16))
@@ -1931,6 +1940,8 @@ struct StagedWgradArgs {
     int stride, pad;
     int64_t P;       // N*Do*Ho*Wo
     int ntiles, G;
+    int x_cseg;            // split x (planar concat): ci tile t lives in plane t * 32 / x_cseg
+    int64_t x_segstride;
 };
 
 template <int TAPS, int PT>
@@ -1952,6 +1963,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_staged_mfma_kernel(StagedWgradAr
     const int h = lane >> 5, cg = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = lane & 3;
     const int lane_off = q * 32 + 16 * cg + 4 * p4;
     const int part = tid & 3;
+    const bf16* const xbase = a.x_cseg ? a.x + (int64_t)((cit * 32) / a.x_cseg) * a.x_segstride : a.x;
+    const int xc0 = a.x_cseg ? (cit * 32) % a.x_cseg : cit * 32;
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += a.G) {
         const int64_t p_base = (int64_t)tile * PT;
@@ -1988,8 +2001,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_staged_mfma_kernel(StagedWgradAr
                           iw = ow * a.stride + kw - a.pad;
                 bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
                 if (tap < TAPS && pv && id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi)
-                    v = *reinterpret_cast<const bf16x8*>(a.x + ((((int64_t)n * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.ldx +
-                                                         cit * 32 + part * 8);
+                    v = *reinterpret_cast<const bf16x8*>(xbase + ((((int64_t)n * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.ldx +
+                                                         xc0 + part * 8);
                 sx[i] = v;
             }
 #pragma unroll
@@ -2109,6 +2122,8 @@ static int wgrad_staged_launch(const void* x, const void* dy, float* dw, void* w
     a.N = g.N; a.Di = g.Di; a.Hi = g.Hi; a.Wi = g.Wi; a.Do = g.Do; a.Ho = g.Ho; a.Wo = g.Wo;
     a.Cin = g.Cin; a.Cout = g.Cout; a.ldx = g.ldx; a.lddy = g.lddy;
     a.stride = g.stride; a.pad = g.pad;
+    a.x_cseg = g.x_cseg; a.x_segstride = g.x_segstride;
+    if (g.x_cseg && (g.x_cseg % 32)) return ru3d_fail(-1, "wgrad_staged: split x needs segments of whole 32-channel tiles");
     a.P = (int64_t)g.N * g.Do * g.Ho * g.Wo;
     const int pt = (g.k == 3) ? 32 : 256;
     const int64_t ntiles = (a.P + pt - 1) / pt;
@@ -2135,13 +2150,17 @@ int wgrad_mfma_launch(const void* x, const void* dy, float* dw, void* ws, size_t
     if (!ws || ws_bytes < need) return ru3d_fail(-1, "wgrad_mfma: workspace too small (%zu < %zu)", ws_bytes, need);
     if (!aligned_to(x, 16) || !aligned_to(dy, 16)) return ru3d_fail(-1, "wgrad_mfma: operands must be 16-byte aligned");
     if (!wgrad_is_halo_form(g)) {
-        if (wgrad_s2_eligible(g)) return wgrad_s2_launch(x, dy, dw, ws, g, st);
+        if (wgrad_s2_eligible(g)) {
+            if (g.x_cseg) return ru3d_fail(-1, "wgrad_mfma: no stride-2 kernel takes a split x");
+            return wgrad_s2_launch(x, dy, dw, ws, g, st);
+        }
         return wgrad_staged_launch(x, dy, dw, ws, g, st);
     }
     {
         WgradSlidePlan sp;
         if (wgrad_slide_plan(g, &sp)) return wgrad_slide_launch(x, dy, dw, ws, g, st);
     }
+    if (g.x_cseg) return ru3d_fail(-1, "wgrad_mfma: only the sliding kernel takes a split x");
     MfmaWgradArgs a;
     a.x = (const bf16*)x;
     a.dy = (const bf16*)dy;

@@ -56,6 +56,7 @@ struct Slide32Args {
     float* stat_slab;
     int N, D, H, W;
     int ldx, ldy, ldr;
+    int64_t yslice;         // elements between the 32-channel output slices (blockIdx.y): 32 dense, the plane distance when split
     int flip;
     int cout_total;                       // Cout of the conv (32 per grid.y slice)
     float slope, inv_slope;               // HAS_BST: LeakyReLU slope of the activation being differentiated
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
         __syncthreads();
 
         // this wave's output rows in plane d0
-        ycur = reinterpret_cast<char*>(a.y + co_b) +
+        ycur = reinterpret_cast<char*>(a.y + (int64_t)blockIdx.y * a.yslice) +
                ((((int64_t)n * a.D + d0) * a.H + h0 + RH * hr) * a.W + w0 + 16 * hw) * (int64_t)a.ldy * 2;
         if constexpr (HAS_X2)
             rcur = reinterpret_cast<const char*>(a.res) +
@@ -528,6 +529,12 @@ int conv_slide_launch(const void* x, const void* w, const float* bias, const voi
     a.stat_slab = stat_slab;
     a.N = g.N; a.D = g.Do; a.H = g.Ho; a.W = g.Wo;
     a.ldx = g.ldx; a.ldy = g.ldy; a.ldr = g.ldr;
+    a.yslice = 32;
+    if (g.y_cseg) {      // planar concat gradient: slice s of the output is plane s
+        if (g.y_cseg != 32 || res || stat_slab) return ru3d_fail(-1, "conv_slide: split output needs 32-channel slices, no residual, no statistics");
+        a.yslice = g.y_segstride;
+    }
+    if (g.x_cseg) return ru3d_fail(-1, "conv_slide: split input not supported");
     a.flip = g.flip;
     a.cout_total = g.Cout;
     a.slope = slope;

@@ -46,6 +46,8 @@ struct Slide64Args {
     float* stat_slab;
     int N, D, H, W;
     int ldx, ldy, ldr;
+    int xsplit;             // planar concat input: channels 32..63 live xdelta_b bytes behind channels 0..31 (pitch ldx = 32)
+    int xdelta_b;
     int flip;
     int cout_total;                       // Cout of the conv (64 per grid.y slice)
     int tiles_h, tiles_w, dsplit, DL, units;
@@ -212,16 +214,21 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
             const int r = piece_row(i), zh = r / WW, zw = r - zh * WW;
             const int gh = h0 - 1 + zh, gw = w0 - 1 + zw;
             const bool okv = piece_valid(i) && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-            voff[i] = okv ? ((gh * a.W + gw) * a.ldx + ((tid + 256 * i) & 7) * 8) * 2 : (int)0x80000000;
+            // (a thread's piece index is the same for every i: 256 i is a multiple of 8.  Split input: the voxel row is two
+            // 64-byte halves in two planes of one buffer - pieces 4..7 carry the planes' distance in their offset)
+            const int pc = (tid + 256 * i) & 7;
+            const int coff = a.xsplit ? (pc >> 2) * a.xdelta_b + (pc & 3) * 16 : pc * 16;
+            voff[i] = okv ? ((gh * a.W + gw) * a.ldx) * 2 + coff : (int)0x80000000;
         }
         const bf16* xs = a.x + (int64_t)n * a.D * (plane_b / 2);
+        const int range_b = a.xsplit ? a.xdelta_b + sample_b : sample_b;
 
         bf16x8 stg[NSTG];
         auto load_piece = [&](int pr, auto ic) {
             constexpr int i = decltype(ic)::value;
             const int d = d0 - 1 + pr;
             const bool dok = d >= 0 && d < a.D;
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xs, (short)0, dok ? sample_b : 0, 0x00020000);
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xs, (short)0, dok ? range_b : 0, 0x00020000);
             stg[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, voff[i], dok ? d * plane_b : 0, 0));
         };
         auto store_piece = [&](int pr, int slot, auto ic) {
@@ -487,6 +494,16 @@ int conv_slide64_launch(const void* x, const void* w, const float* bias, const v
     a.stat_slab = stat_slab;
     a.N = g.N; a.D = g.Do; a.H = g.Ho; a.W = g.Wo;
     a.ldx = g.ldx; a.ldy = g.ldy; a.ldr = g.ldr;
+    a.xsplit = 0; a.xdelta_b = 0;
+    if (g.x_cseg) {
+        // the two 32-channel halves of the concat as planes of one buffer; all offsets stay below 2^31 (top bit = "outside")
+        const int64_t delta_b = g.x_segstride * 2, sample_b = (int64_t)g.Do * g.Ho * g.Wo * g.ldx * 2;
+        if (g.x_cseg != 32 || g.Cin != 64 || g.ldx < 32 || delta_b <= 0 || delta_b + sample_b >= (1ll << 31) || (delta_b % 16))
+            return ru3d_fail(-1, "conv_slide64: split input must be two 32-channel planes less than 2 GiB apart");
+        a.xsplit = 1;
+        a.xdelta_b = (int)delta_b;
+    }
+    if (g.y_cseg) return ru3d_fail(-1, "conv_slide64: split output not supported");
     a.flip = g.flip;
     a.cout_total = g.Cout;
     a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w; a.dsplit = p.dsplit; a.DL = p.DL; a.units = p.units;

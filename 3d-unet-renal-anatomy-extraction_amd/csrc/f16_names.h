@@ -11,6 +11,7 @@
     X(ru3d_conv3d_fwd_in_workspace_bytes) \
     X(ru3d_conv3d_fwd_in) \
     X(ru3d_conv3d_fwd_in_lrelu) \
+    X(ru3d_planar_concat_supported) \
     X(ru3d_conv3d_dgrad) \
     X(ru3d_conv3d_s2_pair_fwd_in_supported) \
     X(ru3d_conv3d_s2_pair_fwd_in_workspace_bytes) \
@@ -56,6 +57,7 @@
 #define ru3d_conv3d_fwd_in_workspace_bytes ru3d_conv3d_fwd_in_workspace_bytes_f16
 #define ru3d_conv3d_fwd_in ru3d_conv3d_fwd_in_f16
 #define ru3d_conv3d_fwd_in_lrelu ru3d_conv3d_fwd_in_lrelu_f16
+#define ru3d_planar_concat_supported ru3d_planar_concat_supported_f16
 #define ru3d_conv3d_dgrad ru3d_conv3d_dgrad_f16
 #define ru3d_conv3d_s2_pair_fwd_in_supported ru3d_conv3d_s2_pair_fwd_in_supported_f16
 #define ru3d_conv3d_s2_pair_fwd_in_workspace_bytes ru3d_conv3d_s2_pair_fwd_in_workspace_bytes_f16

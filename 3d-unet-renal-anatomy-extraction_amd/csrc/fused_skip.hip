@@ -44,6 +44,8 @@ struct SkipArgs {
     int ldx, ldy, ldo;
     int cout;
     float slope;
+    int x_cseg;             // split x (planar concat): 32-channel block ks lives in plane ks * 32 / x_cseg
+    int64_t x_segstride;
 };
 
 // CIN input channels, NPB blocks of 32 output channels
@@ -91,7 +93,9 @@ __global__ __launch_bounds__(256) void skip1x1_in_lrelu_fwd_kernel(SkipArgs a) {
         bf16x8 xb[KS];
         static_for<0, KS>([&](auto kc) {
             constexpr int ks = decltype(kc)::value;
-            xb[ks] = *reinterpret_cast<const bf16x8*>(a.x + vox * a.ldx + ks * 32 + g4 * 8);
+            const bf16* xp = a.x_cseg ? a.x + (int64_t)((ks * 32) / a.x_cseg) * a.x_segstride + (ks * 32) % a.x_cseg
+                                      : a.x + ks * 32;
+            xb[ks] = *reinterpret_cast<const bf16x8*>(xp + vox * a.ldx + g4 * 8);
         });
         bf16x8 yv[NPB];
 #pragma unroll
@@ -132,7 +136,8 @@ __global__ __launch_bounds__(256) void skip1x1_in_lrelu_fwd_kernel(SkipArgs a) {
 bool skip1x1_fused_eligible(const ru3d_tensor* x, const ru3d_tensor* y2, const ru3d_tensor* out, int dtype) {
     static const int mode = getenv("RU3D_FUSED_SKIP") ? atoi(getenv("RU3D_FUSED_SKIP")) : 1;
     if (!mode || dtype != RU3D_BF16) return false;
-    if (!tensor_ok(x) || !tensor_ok(y2) || !tensor_ok(out)) return false;
+    if (!tensor_ok_split(x) || !tensor_ok(y2) || !tensor_ok(out)) return false;
+    if (x->cseg && (x->cseg % 32)) return false;
     if (x->n != y2->n || x->d != y2->d || x->h != y2->h || x->w != y2->w) return false;
     if (out->n != y2->n || out->d != y2->d || out->h != y2->h || out->w != y2->w || out->c != y2->c) return false;
     if (!((x->c == 64 && y2->c == 32) || (x->c == 128 && y2->c == 64))) return false;
@@ -152,6 +157,7 @@ int skip1x1_fused_launch(const ru3d_tensor* x, const void* w, const float* bias,
     a.ldx = x->ld; a.ldy = y2->ld; a.ldo = out->ld;
     a.cout = y2->c;
     a.slope = slope;
+    a.x_cseg = x->cseg; a.x_segstride = x->seg_stride;
     const int64_t groups = a.V / 16 * a.N;
     int64_t blocks = (groups + 3) / 4;
     const int64_t cap = 256 * 8;                        // eight workgroups per CU, each wave walks its groups

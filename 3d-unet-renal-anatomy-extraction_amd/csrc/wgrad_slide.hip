@@ -33,6 +33,8 @@ struct WSlideArgs {
     float* part;
     int N, D, H, W;
     int Cin, Cout, ldx, lddy;
+    int x_cseg;                                // split x (planar concat): ci tile t lives in plane t * 32 / x_cseg
+    int64_t x_segstride;
     int tiles_h, tiles_w, dsplit, DL, units;   // units per (ci, co) pair
     int light_last;                            // EDGE: the last column's far W half lies outside the volume
 };
@@ -89,6 +91,9 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
     // range and comes back as zeros, a plane outside the sample is switched off through the record count - no selects,
     // no address clamps in the loop
     bf16* const sdst = lds + (tid >> 2) * 32 + (tid & 3) * 8;
+    // this workgroup's 32 input channels: a channel offset in the dense tensor, a plane + offset in the split one
+    const bf16* const xbase = a.x_cseg ? a.x + (int64_t)((cit * 32) / a.x_cseg) * a.x_segstride : a.x;
+    const int xc0 = a.x_cseg ? (cit * 32) % a.x_cseg : cit * 32;
     const int xplane_b = a.H * a.W * a.ldx * 2, dplane_b = a.H * a.W * a.lddy * 2;
     const int xsample_b = a.D * xplane_b, dsample_b = a.D * dplane_b;
 
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
             const int r = (tid >> 2) + 64 * i, zh = r / WW, zw = r - zh * WW;
             const int gh = h0 - 1 + zh, gw = w0 - 1 + zw;
             const bool ok = r < PROWS && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W;
-            xvoff[i] = ok ? ((gh * a.W + gw) * a.ldx + cit * 32 + (tid & 3) * 8) * 2 : (int)0x80000000;
+            xvoff[i] = ok ? ((gh * a.W + gw) * a.ldx + xc0 + (tid & 3) * 8) * 2 : (int)0x80000000;
         }
 #pragma unroll
         for (int i = 0; i < NSD; i++) {
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
             dvoff[i] = (w0 + f % TW < a.W) ? (((h0 + f / TW) * a.W + w0 + f % TW) * a.lddy + cot * 32 + (tid & 3) * 8) * 2
                                            : (int)0x80000000;
         }
-        const bf16* xs = a.x + (int64_t)n * a.D * (xplane_b / 2);
+        const bf16* xs = xbase + (int64_t)n * a.D * (xplane_b / 2);
         const bf16* ds = a.dy + (int64_t)n * a.D * (dplane_b / 2);
 
         bf16x8 sx[NSX], sd[NSD];
@@ -319,6 +324,8 @@ int wgrad_slide_launch(const void* x, const void* dy, float* dw, void* ws, const
     a.part = (float*)ws;
     a.N = g.N; a.D = g.Do; a.H = g.Ho; a.W = g.Wo;
     a.Cin = g.Cin; a.Cout = g.Cout; a.ldx = g.ldx; a.lddy = g.lddy;
+    a.x_cseg = g.x_cseg; a.x_segstride = g.x_segstride;
+    if (g.x_cseg && (g.x_cseg % 32)) return ru3d_fail(-1, "wgrad_slide: split x needs segments of whole 32-channel tiles");
     a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w; a.dsplit = p.dsplit; a.DL = p.DL; a.units = p.units;
     a.light_last = (g.Wo % TW) != 0 && (g.Wo % TW) <= 16 && p.tiles_w > 1;
     if (g.Wo % TW) hipLaunchKernelGGL(wgrad3_s1_slide_kernel<true>, dim3(p.G, p.pairs), dim3(256), 0, st, a);

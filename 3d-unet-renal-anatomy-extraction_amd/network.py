@@ -371,11 +371,11 @@ class ResBlock(nn.Module):
     def uses_skip_conv(self):
         return self.in_channels != self.out_channels or self.stride != 1
 
-    def _drop_scale(self, x):
+    def _drop_scale(self, x, planar=False):
         if self.dropout is None or not self.training:
             return None
         p = float(self.dropout.p)
-        n = x.shape[0]
+        n = x.shape[0] // 2 if planar else x.shape[0]
         c = ops.cpad(self.out_channels) if self._pad else self.out_channels
         if self._forced_keep is not None:
             keep = self._forced_keep.to(device=x.device, dtype=torch.float32).reshape(n, -1)
@@ -411,16 +411,17 @@ class ResBlock(nn.Module):
             specs += [(b, N.ROLE_BIAS, 1, cout_seg, 0) for b in biases if b is not None]
         return specs
 
-    def forward(self, x, in_link=None, out_link=None):
+    def forward(self, x, in_link=None, out_link=None, planar=False):
         """in_link / out_link: ops.SkipLink objects Unet passes to the pooling block / the last encoder block of a
-        level (see _ops.SkipLink); standalone use leaves them None."""
+        level (see _ops.SkipLink); standalone use leaves them None.  planar: x is the split concat ops.UpFn made on the
+        full-resolution level ([2N, C/2, D, H, W]: the two halves as planes of one buffer)."""
         if self._native and x.is_cuda:
             skip_w = self.skip_conv.weight if self.uses_skip_conv else None
             skip_b = self.skip_conv.bias if self.uses_skip_conv else None
             return ops.ResBlockFn.apply(x, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias,
-                                        skip_w, skip_b, self.stride, self._drop_scale(x),
+                                        skip_w, skip_b, self.stride, self._drop_scale(x, planar),
                                         self._in_segs if self._pad else 0,
-                                        self._checkpoint and torch.is_grad_enabled(), in_link, out_link)
+                                        self._checkpoint and torch.is_grad_enabled(), in_link, out_link, planar)
         if self._native:
             N.require_device(x, "ResBlock input")
         if self._bn_eval and x.is_cuda and _inference_mode(self):
@@ -671,7 +672,8 @@ class Unet(nn.Module):
             link = None
             if linked:
                 cu = self.up_blocks[i].conv_trans.out_channels
-                link = ops.SkipLink(ops.cpad(cu) if self._pad else cu)
+                cd = self.decode_blocks[i].out_channels if isinstance(self.decode_blocks[i], ResBlock) else 0
+                link = ops.SkipLink(ops.cpad(cu) if self._pad else cu, ops.cpad(cd) if self._pad else cd)
                 x = self.encode_blocks[i](x, out_link=link)
             else:
                 x = self.encode_blocks[i](x)
@@ -681,7 +683,10 @@ class Unet(nn.Module):
         x = self.encode_blocks[-1](x)
         for i in reversed(range(self.num_pool)):
             x = self.up_blocks[i](x, skips[i], links[i]) if linked else self.up_blocks[i](x, skips[i])
-            x = self.decode_blocks[i](x)
+            if linked and getattr(links[i], "planar_out", False):
+                x = self.decode_blocks[i](x, planar=True)       # the concat as two planes (ops.SkipLink.planar_view)
+            else:
+                x = self.decode_blocks[i](x)
         ops._DROP_POOL.clear()
         return self._head(x)
 

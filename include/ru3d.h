@@ -62,7 +62,16 @@ typedef struct ru3d_tensor {
     void* ptr;          /* device pointer to element (0,0,0,0,0)        */
     int32_t n, d, h, w; /* batch and spatial extents                     */
     int32_t c;          /* channels                                      */
-    int32_t ld;         /* voxel pitch in elements (>= c)                */
+    int32_t ld;         /* voxel pitch in elements (>= c; split: >= cseg) */
+    /* Split ("planar") channel layout, cseg != 0: the channels are c / cseg segments of cseg channels, segment s a dense
+     * NDHWC tensor of its own at ptr + s * seg_stride elements (voxel pitch ld): element (n,d,h,w,ch) sits at
+     * ptr[(ch / cseg) * seg_stride + (((n*D+d)*H+h)*W+w) * ld + ch % cseg].  This is how torch.cat((up, skip), dim=1)
+     * (reference network.py:350) is held on the full-resolution level, where the two 32-channel halves interleaved in
+     * one 128-byte row would cost every reader / writer of ONE half double line traffic: both halves stay contiguous
+     * tensors and only the kernels that consume the concat (ru3d_planar_concat_supported lists them) take the pair.
+     * Every other entry point rejects a split tensor. */
+    int32_t cseg;
+    int64_t seg_stride;
 } ru3d_tensor;
 
 int ru3d_version(void);
@@ -128,6 +137,11 @@ int ru3d_conv3d_fwd_in_lrelu(const ru3d_tensor* x, const void* w_packed, const f
                              int stride, int dtype, const float* drop_scale, float* mean, float* scale,
                              const ru3d_tensor* res, const ru3d_tensor* out, float slope, void* ws, size_t ws_bytes,
                              float eps, void* stream);
+/* 1 when a decoder ResBlock whose input is the concat of two `cseg`-channel tensors on an n x d x h x w grid can take that
+ * input as a split tensor through every kernel of its forward and backward: ru3d_conv3d_fwd / _fwd_in / _fwd_in_lrelu (x),
+ * ru3d_skip1x1_in_lrelu_fwd (x), ru3d_conv3d_wgrad k = 3 and k = 1 (x), ru3d_conv3d_s1_dgrad_pair (dx).  cout: the
+ * block's output channels. */
+int ru3d_planar_concat_supported(int n, int d, int h, int w, int cseg, int cout, int dtype);
 /* input gradient of the same conv: dx = conv_dgrad(dy) (+ res).  w_packed made with ROLE_CONV_DGRAD. */
 int ru3d_conv3d_dgrad(const ru3d_tensor* dy, const void* w_packed, const ru3d_tensor* res,
                       const ru3d_tensor* dx, int k, int stride, int dtype, void* ws, size_t ws_bytes,
