@@ -74,6 +74,11 @@ SIGNATURES = {
     "ru3d_conv3d_s2_dgrad_pair": (_i, [_P, _vp, _P, _vp, _P, _P, _i, _vp]),
     "ru3d_conv3d_wgrad_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),
     "ru3d_conv3d_wgrad": (_i, [_P, _P, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    "ru3d_conv3d_wgrad_bias_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),
+    "ru3d_conv3d_wgrad_bias": (_i, [_P, _P, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    "ru3d_head_bwd_supported": (_i, [_P, _P, _P, _i]),
+    "ru3d_head_bwd_workspace_bytes": (_sz, [_P, _i]),
+    "ru3d_head_bwd": (_i, [_P, _P, _vp, _i, _P, _vp, _vp, _vp, _sz, _i, _vp]),
     "ru3d_convtranspose3d_k3s2p1_fwd": (_i, [_P, _vp, _vp, _P, _i, _vp]),
     "ru3d_convtranspose3d_k3s2p1_fwd_in_workspace_bytes": (_sz, [_P, _P, _i]),
     "ru3d_convtranspose3d_k3s2p1_fwd_in": (_i, [_P, _vp, _vp, _P, _vp, _vp, _vp, _sz, _f, _i, _vp]),

@@ -373,6 +373,40 @@ def conv_wgrad(x, dy, k, stride, key=None):
     return dw
 
 
+def conv_wgrad_bias(x, dy, k, stride, key=None):
+    """(dW, db) of a conv with bias from one entry point (the stem's kernel sums dy while it reads it)."""
+    cout, cin = dy.shape[1], x.shape[1]
+    dw = _grad_out(key, (cout, cin, k, k, k), x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device)
+    dx, ddy = desc(x), desc(dy)
+    code = N.dtype_code(x.dtype)
+    ws = N.workspace(N.lib.ru3d_conv3d_wgrad_bias_workspace_bytes(ref(dx), ref(ddy), k, stride, code), x.device)
+    check(N.lib.ru3d_conv3d_wgrad_bias(ref(dx), ref(ddy), ptr(dw), ptr(db), ptr(ws), ws.numel(), k, stride, code, stream()),
+          "conv3d_wgrad_bias")
+    return dw, db
+
+
+def head_bwd(x, gy, weight, want_bias, key=None):
+    """The 1x1x1 head's backward in one pass (ru3d_head_bwd): gy = dlogits as the loss left them (fp32, NDHWC) ->
+    (dx, dW, db), or None when the shapes have no fused kernel."""
+    if gy.dtype != torch.float32 or x.dtype == torch.float32 or not N.is_ndhwc(gy) or weight.dtype != torch.float32:
+        return None
+    n, c, d, h, w = x.shape
+    dx = N.new_act(n, c, d, h, w, x.dtype, x.device)
+    ddx, dg, dxx = desc(x), desc(gy), desc(dx)
+    code = N.dtype_code(x.dtype)
+    if not N.lib.ru3d_head_bwd_supported(ref(ddx), ref(dg), ref(dxx), code):
+        return None
+    cout, cin = weight.shape[0], weight.shape[1]
+    dw = _grad_out(key, (cout, cin, 1, 1, 1), x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device) if want_bias else None
+    ws = N.workspace(N.lib.ru3d_head_bwd_workspace_bytes(ref(ddx), code), x.device)
+    wd = weight.detach()
+    check(N.lib.ru3d_head_bwd(ref(ddx), ref(dg), ptr(wd if wd.is_contiguous() else wd.contiguous()), cin, ref(dxx), ptr(dw),
+                              ptr(db), ptr(ws), ws.numel(), code, stream()), "head_bwd")
+    return dx, dw, db
+
+
 def convt_fwd(x, pw, bias, cout):
     n, _, d, h, w = x.shape
     y = N.new_act(n, cout, 2 * d, 2 * h, 2 * w, x.dtype, x.device)
@@ -908,6 +942,7 @@ class ConvFn(torch.autograd.Function):
         ctx.storage_dtype = storage_dtype
         ctx.in_dtype = x.dtype
         ctx.wkey = weight.data_ptr() if not (cout_seg or cin_seg) else None
+        ctx.weight_ref = weight if (k == 1 and cout <= 4) else None      # the head's fused backward reads the fp32 parameter
         return y
 
     @staticmethod
@@ -915,12 +950,25 @@ class ConvFn(torch.autograd.Function):
         xin, pwd = ctx.saved_tensors
         sd = ctx.storage_dtype
         cout, cin, cout_seg, cin_seg = ctx.dims
+        if (ctx.k == 1 and ctx.stride == 1 and cout <= 4 and not cout_seg and all(ctx.needs_input_grad[:2])
+                and ctx.weight_ref is not None):
+            # the head: input, weight and bias gradient from one pass over (x, dlogits)
+            fused = head_bwd(xin, gy, ctx.weight_ref, ctx.has_bias and ctx.needs_input_grad[2],
+                             key=None if cin_seg else ctx.wkey)
+            if fused is not None:
+                gx, gw, gb = fused
+                if gx.dtype != ctx.in_dtype:
+                    gx = gx.to(ctx.in_dtype)
+                return gx, gw, gb, None, None, None, None, None
         gy = as_grad(gy, sd)
         gx = gw = gb = None
         with _OnSide(gy.device):      # stem / head: full-resolution tensors, main stream
-            if ctx.needs_input_grad[1]:
+            if ctx.needs_input_grad[1] and ctx.has_bias and ctx.needs_input_grad[2] and not (cout_seg or cin_seg) \
+                    and sd != torch.float32:
+                gw, gb = conv_wgrad_bias(xin, gy, ctx.k, ctx.stride, key=ctx.wkey)       # the stem: db from the same pass
+            elif ctx.needs_input_grad[1]:
                 gw = unpad_wgrad(conv_wgrad(xin, gy, ctx.k, ctx.stride, key=ctx.wkey), cout, cin, cout_seg, cin_seg)
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+            if gb is None and ctx.has_bias and ctx.needs_input_grad[2]:
                 gb = channel_sum(gy)[:cout]
         if ctx.needs_input_grad[0]:
             gx = conv_dgrad(gy, pwd, tuple(xin.shape), ctx.k, ctx.stride)

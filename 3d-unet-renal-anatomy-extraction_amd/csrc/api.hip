@@ -657,6 +657,59 @@ extern "C" int ru3d_conv3d_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, fl
 }
 
 
+// ---- weight gradient AND bias gradient (= sum of dy over samples and voxels) of a conv behind one entry point: the stem's
+// MFMA weight-gradient kernel delivers the bias row from the same pass over dy; elsewhere ru3d_conv3d_wgrad + ru3d_channel_sum
+extern "C" size_t ru3d_conv3d_wgrad_bias_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* dy, int k, int stride,
+                                                         int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_wgrad_bias_workspace_bytes_f16(x, dy, k, stride, dtype));
+    if (!wgrad_shapes_ok(x, dy, k, stride)) return 0;
+    const size_t a = ru3d_conv3d_wgrad_workspace_bytes(x, dy, k, stride, dtype), b = ru3d_reduce_workspace_bytes(dy);
+    return a > b ? a : b;
+}
+
+extern "C" int ru3d_conv3d_wgrad_bias(const ru3d_tensor* x, const ru3d_tensor* dy, float* dw, float* db, void* ws,
+                                      size_t ws_bytes, int k, int stride, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_wgrad_bias_f16(x, dy, dw, db, ws, ws_bytes, k, stride, dtype, stream));
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE((k == 1 || k == 3) && (stride == 1 || stride == 2), "conv3d_wgrad_bias: k=%d stride=%d unsupported", k, stride);
+    RU3D_REQUIRE(wgrad_shapes_ok(x, dy, k, stride) && tensor_ok(x), "conv3d_wgrad_bias: x/dy shape mismatch");
+    RU3D_REQUIRE(dw && db && dtype_ok(dtype), "conv3d_wgrad_bias: bad argument");
+    RU3D_REQUIRE(ws && ws_bytes >= ru3d_conv3d_wgrad_bias_workspace_bytes(x, dy, k, stride, dtype),
+                 "conv3d_wgrad_bias: workspace too small");
+    WgradGeom g = make_wgrad(x, dy, k, stride);
+    if (stem_wgrad_gives_bias(g, dtype))
+        return stem_wgrad_launch(x->ptr, dy->ptr, dw, ws, ws_bytes, g, dtype, as_stream(stream), db);
+    int rc = ru3d_conv3d_wgrad(x, dy, dw, ws, ws_bytes, k, stride, dtype, stream);
+    if (rc) return rc;
+    return ru3d_channel_sum(dy, db, ws, ws_bytes, dtype, stream);
+}
+
+// ---- the 1x1x1 head's whole backward (reference network.py:547 fc): dlogits (fp32, as the loss kernel leaves it) -> dx, dW, db
+extern "C" int ru3d_head_bwd_supported(const ru3d_tensor* x, const ru3d_tensor* dlogits, const ru3d_tensor* dx, int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_head_bwd_supported_f16(x, dlogits, dx, dtype));
+    if (!tensor_ok(x) || !tensor_ok(dlogits) || !tensor_ok(dx)) return 0;
+    if (x->n != dlogits->n || x->d != dlogits->d || x->h != dlogits->h || x->w != dlogits->w) return 0;
+    if (dx->n != x->n || dx->d != x->d || dx->h != x->h || dx->w != x->w || dx->c != x->c) return 0;
+    if ((x->ld % 8) || (dx->ld % 8) || ((((uintptr_t)x->ptr) | ((uintptr_t)dx->ptr)) % 16) || (((uintptr_t)dlogits->ptr) % 4)) return 0;
+    return head_bwd_eligible(x->c, dlogits->c, dtype) ? 1 : 0;
+}
+
+extern "C" size_t ru3d_head_bwd_workspace_bytes(const ru3d_tensor* x, int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_head_bwd_workspace_bytes_f16(x, dtype));
+    return tensor_ok(x) ? head_bwd_ws_bytes(nvox(x), x->c) : 0;
+}
+
+extern "C" int ru3d_head_bwd(const ru3d_tensor* x, const ru3d_tensor* dlogits, const float* weight, int cin_real,
+                             const ru3d_tensor* dx, float* dw, float* db, void* ws, size_t ws_bytes, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_head_bwd_f16(x, dlogits, weight, cin_real, dx, dw, db, ws, ws_bytes, dtype, stream));
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(ru3d_head_bwd_supported(x, dlogits, dx, dtype), "head_bwd: shapes have no fused kernel (ask ru3d_head_bwd_supported first)");
+    RU3D_REQUIRE(weight && dw && ws && cin_real > 0 && cin_real <= x->c, "head_bwd: bad argument");
+    RU3D_REQUIRE(ws_bytes >= head_bwd_ws_bytes(nvox(x), x->c), "head_bwd: workspace too small");
+    return head_bwd_launch(x->ptr, x->ld, (const float*)dlogits->ptr, dlogits->ld, weight, cin_real, x->c, dlogits->c, dx->ptr,
+                           dx->ld, dw, db, ws, nvox(x), as_stream(stream));
+}
+
 // --------------------------------------------------------------------------- ConvTranspose3d(k3,s2,p1) + far pad
 static bool convt_shapes_ok(const ru3d_tensor* x, const ru3d_tensor* y) {
     return tensor_ok(x) && tensor_ok(y) && x->n == y->n && y->d == 2 * x->d && y->h == 2 * x->h && y->w == 2 * x->w;

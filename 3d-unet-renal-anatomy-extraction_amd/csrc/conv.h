@@ -186,7 +186,13 @@ int head_dgrad_launch(const void* dy, const void* w, void* dx, const ConvGeom& g
 bool stem_wgrad_eligible(const WgradGeom& g);
 size_t stem_wgrad_ws_bytes(const WgradGeom& g);
 int stem_wgrad_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, const WgradGeom& g,
-                      int dtype, hipStream_t st);
+                      int dtype, hipStream_t st, float* db = nullptr);
+bool stem_wgrad_gives_bias(const WgradGeom& g, int dtype);
+// the head's whole backward in one pass over (a, dlogits fp32): dx, dW, db
+bool head_bwd_eligible(int Cin, int Cout, int dtype);
+size_t head_bwd_ws_bytes(int64_t P, int Cin);
+int head_bwd_launch(const void* a, int lda, const float* dlog, int ldd, const float* w, int cin_real, int Cin, int Cout,
+                    void* dx, int lddx, float* dw, float* db, void* ws, int64_t P, hipStream_t st);
 bool head_wgrad_eligible(const WgradGeom& g, int dtype);
 size_t head_wgrad_ws_bytes(const WgradGeom& g);
 int head_wgrad_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, const WgradGeom& g,

@@ -27,6 +27,11 @@
     X(ru3d_in_lrelu_bwd_apply) \
     X(ru3d_conv3d_wgrad_workspace_bytes) \
     X(ru3d_conv3d_wgrad) \
+    X(ru3d_conv3d_wgrad_bias_workspace_bytes) \
+    X(ru3d_conv3d_wgrad_bias) \
+    X(ru3d_head_bwd_supported) \
+    X(ru3d_head_bwd_workspace_bytes) \
+    X(ru3d_head_bwd) \
     X(ru3d_convtranspose3d_k3s2p1_fwd) \
     X(ru3d_convtranspose3d_k3s2p1_dgrad) \
     X(ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes) \
@@ -73,6 +78,11 @@
 #define ru3d_in_lrelu_bwd_apply ru3d_in_lrelu_bwd_apply_f16
 #define ru3d_conv3d_wgrad_workspace_bytes ru3d_conv3d_wgrad_workspace_bytes_f16
 #define ru3d_conv3d_wgrad ru3d_conv3d_wgrad_f16
+#define ru3d_conv3d_wgrad_bias_workspace_bytes ru3d_conv3d_wgrad_bias_workspace_bytes_f16
+#define ru3d_conv3d_wgrad_bias ru3d_conv3d_wgrad_bias_f16
+#define ru3d_head_bwd_supported ru3d_head_bwd_supported_f16
+#define ru3d_head_bwd_workspace_bytes ru3d_head_bwd_workspace_bytes_f16
+#define ru3d_head_bwd ru3d_head_bwd_f16
 #define ru3d_convtranspose3d_k3s2p1_fwd ru3d_convtranspose3d_k3s2p1_fwd_f16
 #define ru3d_convtranspose3d_k3s2p1_dgrad ru3d_convtranspose3d_k3s2p1_dgrad_f16
 #define ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes ru3d_convtranspose3d_k3s2p1_wgrad_workspace_bytes_f16

@@ -410,9 +410,9 @@ __device__ __forceinline__ bf16x8 stem_tr_frag(const bf16* p) {
 
 __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                                               float* __restrict__ part, WgradGeom g, int tiles_h,
-                                                              int tiles_w, int ntiles) {
+                                                              int tiles_w, int ntiles, float* __restrict__ bias_part) {
     __shared__ __attribute__((aligned(16))) bf16 ds[256 * 32];            // [position][32 co]
-    __shared__ __attribute__((aligned(16))) bf16 xs[(3 * 3 * 10 + 1) * 32];   // [kw][kd][row][32 cols] + a zero row
+    __shared__ __attribute__((aligned(16))) bf16 xs[(3 * 3 * 10 + 2) * 32];   // [kw][kd][row][32 cols] + a zero row + a row of ones
     __shared__ float red[4][16][64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -422,8 +422,13 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const bf16* __rest
     // A fragment base of this lane: tap = lane & 31 (rows 27..31 read the zero row)
     const int tap = lane & 31;
     const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-    const int abase = tap < 27 ? (((kw * 3 + kd) * 10 + kh) * 32 + 8 * h) : (90 * 32);
-    if (tid < 32) xs[90 * 32 + tid] = (bf16)0.f;
+    // rows 28..31 of the A operand are zeros; row 27 is ONES: its output row is sum_pos dy[pos][co] - the conv's bias
+    // gradient from the pass that reads dy anyway (was a separate reduction over dy: 62 + 8 us at 2 x 128^3)
+    const int abase = tap < 27 ? (((kw * 3 + kd) * 10 + kh) * 32 + 8 * h) : ((tap == 27 ? 91 : 90) * 32);
+    if (tid < 32) {
+        xs[90 * 32 + tid] = (bf16)0.f;
+        xs[91 * 32 + tid] = (bf16)1.f;
+    }
 
     f32x16 acc;
 #pragma unroll
@@ -478,6 +483,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const bf16* __rest
         const float s = (red[0][i][ln] + red[1][i][ln]) + (red[2][i][ln] + red[3][i][ln]);
         const int tp = (i & 3) + 8 * (i >> 2) + 4 * (ln >> 5), co = ln & 31;
         if (tp < 27) part[((int64_t)blockIdx.x * 27 + tp) * g.Cout + co0 + co] = s;
+        else if (tp == 27 && bias_part) bias_part[(int64_t)blockIdx.x * g.Cout + co0 + co] = s;
     }
 }
 
@@ -502,24 +508,34 @@ static int stem_chunks(const WgradGeom& g) {
 }
 
 size_t stem_wgrad_ws_bytes(const WgradGeom& g) {
-    // upper bound over both kernels (the MFMA form writes at most STEM_MF_BLOCKS slabs)
+    // upper bound over both kernels (the MFMA form writes at most STEM_MF_BLOCKS slabs, 28 rows each with the bias row)
     const size_t chunks = (size_t)stem_chunks(g) > (size_t)STEM_MF_BLOCKS ? (size_t)stem_chunks(g) : (size_t)STEM_MF_BLOCKS;
-    return chunks * 27 * g.Cout * sizeof(float);
+    return chunks * 28 * g.Cout * sizeof(float);
+}
+
+// the MFMA form can deliver the bias gradient (sum of dy over all positions) from the same pass
+bool stem_wgrad_gives_bias(const WgradGeom& g, int dtype) {
+    const int64_t ntiles = (int64_t)g.N * g.Do * ((g.Ho + 7) / 8) * ((g.Wo + 31) / 32);
+    return stem_wgrad_eligible(g) && stem_wgrad_mfma_ok(g, dtype) && ntiles <= 0x7fffffff;
 }
 
 int stem_wgrad_launch(const void* x, const void* dy, float* dw, void* ws, size_t ws_bytes, const WgradGeom& g,
-                      int dtype, hipStream_t st) {
+                      int dtype, hipStream_t st, float* db) {
     if (!ws || ws_bytes < stem_wgrad_ws_bytes(g)) return ru3d_fail(-1, "stem_wgrad: workspace too small");
+    if (db && !stem_wgrad_gives_bias(g, dtype)) return ru3d_fail(-1, "stem_wgrad: no bias gradient from this form");
     if (stem_wgrad_mfma_ok(g, dtype)) {
         const int blocks = stem_mfma_blocks(g);
         const int tiles_h = (g.Ho + 7) / 8, tiles_w = (g.Wo + 31) / 32;
         const int64_t ntiles = (int64_t)g.N * g.Do * tiles_h * tiles_w;
         if (ntiles <= 0x7fffffff) {
+            float* bias_part = db ? (float*)ws + (size_t)blocks * 27 * g.Cout : nullptr;
             hipLaunchKernelGGL(stem_wgrad_mfma_kernel, dim3(blocks, g.Cout / 32), dim3(256), 0, st, (const bf16*)x,
-                               (const bf16*)dy, (float*)ws, g, tiles_h, tiles_w, (int)ntiles);
+                               (const bf16*)dy, (float*)ws, g, tiles_h, tiles_w, (int)ntiles, bias_part);
             int rc = ru3d_check_launch("stem_wgrad_mfma");
             if (rc) return rc;
-            return wgrad_reduce_launch((const float*)ws, dw, blocks, 27, 1, g.Cout, g.s_o, g.s_i, st);
+            rc = wgrad_reduce_launch((const float*)ws, dw, blocks, 27, 1, g.Cout, g.s_o, g.s_i, st);
+            if (rc || !db) return rc;
+            return wgrad_reduce_launch(bias_part, db, blocks, 1, 1, g.Cout, 1, 1, st);
         }
     }
     const int chunks = stem_chunks(g);
@@ -595,6 +611,141 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const T* __restrict__ x
                 part[((int64_t)blockIdx.x * g.Cin + cg * VEC + i) * g.Cout + c] = s;
             }
     }
+}
+
+// --------------------------------------------------------------------------- head backward, fused (k1, Cout <= 4)
+// The gradient of the logits arrives as fp32 from the loss kernel; the unfused path cast it to the storage type (one pass),
+// then read that copy three times: weight gradient, bias gradient (a channel sum) and input gradient - 253 us in six
+// launches at 2 x 128^3.  Here one pass reads a = the head's input and dlogits once, rounds dlogits to the storage type in
+// registers (the value every unfused consumer saw) and produces
+//     dx[v][ci]  = sum_co d[v][co] * w[co][ci]        (stored, 16 bytes per lane)
+//     dW[co][ci] = sum_v  a[v][ci] * d[v][co]          (per-thread fp32 sums -> per-block partial -> fixed-order finalize)
+//     db[co]     = sum_v  d[v][co]
+// Thread = (voxel lane, 8 input channels); the G = Cin / 8 lanes of a voxel share its <= 4 gradient values.
+constexpr int HB_U = 4;
+__global__ __launch_bounds__(256) void head_bwd_kernel(const bf16* __restrict__ a, int lda, const float* __restrict__ dlog,
+                                                       int ldd, const float* __restrict__ w, int cin_real, int Cin, int Cout,
+                                                       bf16* __restrict__ dx, int lddx, float* __restrict__ part, int64_t P) {
+    __shared__ float sh[256][33];
+    const int G = Cin / 8, vpb = 256 / G;
+    const int tid = threadIdx.x, cg = tid % G, vl = tid / G;
+    float wr[4][8];      // the packed (16-bit) weight the unfused input gradient read
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int ci = cg * 8 + j;
+            wr[c][j] = (c < Cout && ci < cin_real) ? (float)(bf16)w[c * cin_real + ci] : 0.f;
+        }
+    float aw[4][8], ab[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        ab[c] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) aw[c][j] = 0.f;
+    }
+    const int64_t stride = (int64_t)gridDim.x * vpb;
+    for (int64_t p0 = (int64_t)blockIdx.x * vpb + vl; p0 < P; p0 += HB_U * stride) {
+        bf16x8 xv[HB_U];
+        float dv[HB_U][4];
+#pragma unroll
+        for (int u = 0; u < HB_U; u++) {
+            const int64_t p = p0 + u * stride;
+            const bool ok = p < P;
+            const int64_t pp = ok ? p : p0;
+            xv[u] = *reinterpret_cast<const bf16x8*>(a + pp * lda + cg * 8);
+#pragma unroll
+            for (int c = 0; c < 4; c++) dv[u][c] = (ok && c < Cout) ? (float)(bf16)dlog[pp * ldd + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < HB_U; u++) {
+            const int64_t p = p0 + u * stride;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    o[j] = fmaf(dv[u][c], wr[c][j], o[j]);                  // head_dgrad_kernel's order
+                    aw[c][j] = fmaf((float)xv[u][j], dv[u][c], aw[c][j]);
+                }
+                ab[c] += dv[u][c];
+            }
+            if (p < P) store_vec<bf16, 8>(dx + p * lddx + cg * 8, o);
+        }
+    }
+    // per-block partial: the voxel lanes of a channel group in a fixed order
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) sh[tid][c * 8 + j] = aw[c][j];
+    sh[tid][32] = 0.f;
+    __syncthreads();
+    float* pp = part + (int64_t)blockIdx.x * (4 * Cin + 4);
+    for (int e = tid; e < 4 * Cin; e += 256) {
+        const int c = e / Cin, ci = e % Cin, g8 = ci / 8, j = ci % 8;
+        float s = 0.f;
+        for (int l = 0; l < vpb; l++) s += sh[l * G + g8][c * 8 + j];
+        pp[e] = s;
+    }
+    __syncthreads();
+    if (cg == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) sh[vl][c] = ab[c];
+    }
+    __syncthreads();
+    if (tid < 4) {
+        float s = 0.f;
+        for (int l = 0; l < vpb; l++) s += sh[l][tid];
+        pp[4 * Cin + tid] = s;
+    }
+}
+
+// dW[co][ci < cin_real], db[co] = sums of the per-block partials in block order (double)
+__global__ __launch_bounds__(256) void head_bwd_finalize_kernel(const float* __restrict__ part, int blocks, int Cin,
+                                                                int cin_real, int Cout, float* __restrict__ dw,
+                                                                float* __restrict__ db) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // one wave per output value
+    const int row = 4 * Cin + 4;
+    if (e >= row) return;
+    double acc = 0.0;
+    for (int b = lane; b < blocks; b += 64) acc += (double)part[(int64_t)b * row + e];
+    acc = wave_sum_d(acc);
+    if (lane) return;
+    if (e < 4 * Cin) {
+        const int c = e / Cin, ci = e % Cin;
+        if (c < Cout && ci < cin_real) dw[c * cin_real + ci] = (float)acc;
+    } else if (e - 4 * Cin < Cout && db) {
+        db[e - 4 * Cin] = (float)acc;
+    }
+}
+
+static int head_bwd_blocks(int64_t P, int Cin) {
+    const int vpb = 256 / (Cin / 8);
+    int64_t b = (P + (int64_t)vpb * HB_U - 1) / ((int64_t)vpb * HB_U);
+    return (int)(b < 2048 ? (b < 1 ? 1 : b) : 2048);
+}
+
+bool head_bwd_eligible(int Cin, int Cout, int dtype) {
+    static const int mode = getenv("RU3D_HEAD_FUSED") ? atoi(getenv("RU3D_HEAD_FUSED")) : 1;
+    const int G = Cin / 8;
+    return mode && dtype == RU3D_BF16 && Cout >= 1 && Cout <= 4 && (Cin % 8) == 0 && G >= 1 && G <= 64 && (G & (G - 1)) == 0;
+}
+
+size_t head_bwd_ws_bytes(int64_t P, int Cin) { return (size_t)head_bwd_blocks(P, Cin) * (4 * Cin + 4) * sizeof(float); }
+
+int head_bwd_launch(const void* a, int lda, const float* dlog, int ldd, const float* w, int cin_real, int Cin, int Cout,
+                    void* dx, int lddx, float* dw, float* db, void* ws, int64_t P, hipStream_t st) {
+    const int blocks = head_bwd_blocks(P, Cin);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(blocks), dim3(256), 0, st, (const bf16*)a, lda, dlog, ldd, w, cin_real, Cin, Cout,
+                       (bf16*)dx, lddx, (float*)ws, P);
+    int rc = ru3d_check_launch("head_bwd");
+    if (rc) return rc;
+    const int vals = 4 * Cin + 4;
+    hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3((vals + 3) / 4), dim3(256), 0, st, (const float*)ws, blocks, Cin,
+                       cin_real, Cout, dw, db);
+    return ru3d_check_launch("head_bwd_finalize");
 }
 
 bool head_wgrad_eligible(const WgradGeom& g, int dtype) {

@@ -176,6 +176,21 @@ size_t ru3d_conv3d_wgrad_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor
 int ru3d_conv3d_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, float* dw, void* ws, size_t ws_bytes,
                       int k, int stride, int dtype, void* stream);
 
+/* The same weight gradient AND the conv's bias gradient db[co] = sum over samples and voxels of dy (autograd of the bias of
+ * network.py:541 conv / any nn.Conv3d) behind one entry point: the stem's MFMA kernel delivers db from its own pass over dy
+ * (an extra all-ones row of its im2col operand); other shapes run ru3d_conv3d_wgrad + ru3d_channel_sum. */
+size_t ru3d_conv3d_wgrad_bias_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* dy, int k, int stride, int dtype);
+int ru3d_conv3d_wgrad_bias(const ru3d_tensor* x, const ru3d_tensor* dy, float* dw, float* db, void* ws, size_t ws_bytes,
+                           int k, int stride, int dtype, void* stream);
+/* The whole backward of the 1x1x1 head conv (network.py:547 `fc`, Cout <= 4) in one pass: x = the head's input (16-bit
+ * storage), dlogits = the loss's gradient as fp32 [N][D][H][W][Cout] (it is rounded to the storage type in registers, the
+ * value the unfused path's cast stored), weight = the fp32 parameter [Cout][cin_real] (cin_real < x->c: padded channels),
+ * -> dx (storage type, pad lanes 0), dw [Cout][cin_real], db [Cout] (may be NULL). */
+int ru3d_head_bwd_supported(const ru3d_tensor* x, const ru3d_tensor* dlogits, const ru3d_tensor* dx, int dtype);
+size_t ru3d_head_bwd_workspace_bytes(const ru3d_tensor* x, int dtype);
+int ru3d_head_bwd(const ru3d_tensor* x, const ru3d_tensor* dlogits, const float* weight, int cin_real, const ru3d_tensor* dx,
+                  float* dw, float* db, void* ws, size_t ws_bytes, int dtype, void* stream);
+
 /* nn.ConvTranspose3d(k3,s2,p1) followed by ConstantPad3d((0,1,0,1,0,1),0) (network.py:312-314):
  * y has extents 2*x.{d,h,w}; its far planes are written as exact zeros (no bias there). */
 int ru3d_convtranspose3d_k3s2p1_fwd(const ru3d_tensor* x, const void* w_packed, const float* bias,
