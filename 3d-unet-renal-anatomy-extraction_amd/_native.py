@@ -119,6 +119,8 @@ SIGNATURES = {
     "ru3d_predict_merge": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ru3d_adam_multi": (_i, [_vp, _vp, _i, _i, _f, _f, _f, _f, _f, _f, _f, _vp]),
     "ru3d_adam_multi_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "ru3d_adam_multi_amp": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "ru3d_amp_update": (_i, [_vp, _f, _f, _i, _f, _f, _vp]),
     "ru3d_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _f, _f, _vp]),
     "ru3d_augment_workspace_bytes": (_sz, [_i, _i, _i]),
     "ru3d_augment_label_presence": (_i, [_vp, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int32),

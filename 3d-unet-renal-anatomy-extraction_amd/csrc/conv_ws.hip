@@ -220,6 +220,7 @@ int conv_ws_slices(int N, int D, int H, int W, int Cin, int Cout) {
     if (!mode || (Cin % 32) || (Cout % 32)) return 0;
     const int64_t V = (int64_t)D * H * W, PV = (int64_t)(D + 2) * (H + 2) * (W + 2);
     if (V > WS_MAXT * 64 || PV > WS_ROWS || V < 64) return 0;
+    if (W < 2 || H * W < 2) return 0;      // the kernel's magic-number divisions hold for divisors >= 2
     // weights dominate: the point of the form is to read them once per sample
     if ((int64_t)Cin * Cout < 256 * 256) return 0;
     // ... which pays where the tile kernels cut a sample into many boxes: 8^3 is two 4 x 8 x 8 boxes (26.8 us there, 32.5

@@ -501,6 +501,61 @@ extern "C" int ru3d_adam_multi_dev(const ru3d_adam_tensor* tensors, const int32_
     return ru3d_check_launch("adam_multi_dev");
 }
 
+// ---- fp16 training inside a captured step: the loss scaler lives on the device (ru3d_amp_state, see ru3d.h).  The update
+// kernel skips itself when the gradient check found an overflow, takes 1 / scale and the number of steps really taken
+// from the state block (bias corrections from that count), and a one-thread kernel then moves the scaler: halve + reset
+// on overflow, count a clean step and double after `growth_interval` of them otherwise - apex's schedule
+// (reference trainer.py:492-493, 538-542), without the per-step read-back that kept the fp16 step out of a hipGraph.
+__global__ __launch_bounds__(256) void adam_multi_amp_kernel(const ru3d_adam_tensor* __restrict__ tensors,
+                                                             const int32_t* __restrict__ block_map, int chunk_elems,
+                                                             const float* __restrict__ hyper,
+                                                             const ru3d_amp_state* __restrict__ amp) {
+    if (amp->found_inf != 0.f) return;                                   // overflow: the step is skipped
+    const int t = __float_as_int(hyper[5]) + amp->steps + 1;             // Adam step number of this update
+    const double bc1 = 1.0 - pow((double)hyper[1], (double)t), bc2 = 1.0 - pow((double)hyper[2], (double)t);
+    adam_multi_body(tensors, block_map, chunk_elems, hyper[0], hyper[1], hyper[2], hyper[3], (float)bc1, sqrtf((float)bc2),
+                    amp->inv_scale);
+}
+
+__global__ void amp_update_kernel(ru3d_amp_state* amp, float growth, float backoff, int interval, float min_scale,
+                                  float max_scale) {
+    if (threadIdx.x || blockIdx.x) return;
+    if (amp->found_inf != 0.f) {
+        amp->scale = fmaxf(amp->scale * backoff, min_scale);
+        amp->tracker = 0;
+        amp->skipped += 1;
+    } else {
+        amp->steps += 1;
+        amp->tracker += 1;
+        if (amp->tracker >= interval) {
+            amp->scale = fminf(amp->scale * growth, max_scale);
+            amp->tracker = 0;
+        }
+    }
+    amp->inv_scale = 1.f / amp->scale;
+    amp->found_inf = 0.f;
+}
+
+extern "C" int ru3d_adam_multi_amp(const ru3d_adam_tensor* tensors, const int32_t* block_map, int nblocks, int chunk_elems,
+                                   const float* hyper, const ru3d_amp_state* amp, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(tensors && block_map && hyper && amp && nblocks > 0 && chunk_elems >= 1024 && (chunk_elems % 1024) == 0,
+                 "adam_multi_amp: bad argument (chunk_elems must be a positive multiple of 1024)");
+    hipLaunchKernelGGL(adam_multi_amp_kernel, dim3((unsigned)nblocks), dim3(256), 0, as_stream(stream), tensors, block_map,
+                       chunk_elems, hyper, amp);
+    return ru3d_check_launch("adam_multi_amp");
+}
+
+extern "C" int ru3d_amp_update(ru3d_amp_state* amp, float growth_factor, float backoff_factor, int growth_interval,
+                               float min_scale, float max_scale, void* stream) {
+    Ru3dDeviceGuard dev_guard(stream);
+    RU3D_REQUIRE(amp && growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval > 0 &&
+                     min_scale > 0.f && max_scale >= min_scale, "amp_update: bad argument");
+    hipLaunchKernelGGL(amp_update_kernel, dim3(1), dim3(64), 0, as_stream(stream), amp, growth_factor, backoff_factor,
+                       growth_interval, min_scale, max_scale);
+    return ru3d_check_launch("amp_update");
+}
+
 // --------------------------------------------------------------------------- loss scaling (fp16 storage)
 // Dynamic loss scaling of the reference's mixed-precision mode (apex O1, trainer.py:492-493, 538-542): gradients are
 // computed on `scale * loss`; before the optimizer step every gradient is checked for inf / nan (an overflow skips the

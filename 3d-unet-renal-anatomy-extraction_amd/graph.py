@@ -15,8 +15,9 @@ What makes a captured step the SAME computation as the eager one, step after ste
   * gradients, activations and workspaces live at fixed addresses of the graph's private memory pool.
 tests/test_gpu_graph.py holds the bit-equality of graphed and eager training.
 
-Not captured (the caller falls back to the eager step): a batch of another shape, fp16 loss scaling (its skip-on-overflow
-is a host decision), the multi-GPU gradient exchange.
+fp16 storage (round 4): the dynamic loss scaler lives on the device while a step is captured (`ru3d_amp_state`: the update
+kernel skips itself on overflow, `ru3d_amp_update` applies apex's schedule), so the reference's own training mode replays
+too.  Not captured (the caller falls back to the eager step): a batch of another shape, the multi-GPU gradient exchange.
 
     step = GraphedTrainStep(model, criterion, optimizer)
     for x, y in loader:
@@ -35,11 +36,12 @@ _RING = 8      # pinned host blocks in flight: a replay's scalars stay untouched
 
 
 class GraphedTrainStep:
-    def __init__(self, model, criterion, optimizer, warmup=2):
+    def __init__(self, model, criterion, optimizer, warmup=2, scaler=None):
         if not isinstance(optimizer, _optim.Adam):
             raise TypeError("GraphedTrainStep needs optim.Adam (its update kernel reads the per-step scalars from "
                             "device memory)")
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.scaler = scaler         # optim.LossScaler (fp16 storage): its state moves to the device for the capture
         self.warmup = max(1, int(warmup))    # the first Adam step creates the moment buffers
         self.graph = None
         self.key = None
@@ -51,8 +53,14 @@ class GraphedTrainStep:
         self.optimizer.zero_grad(set_to_none=True)
         logits = self.model(x)
         loss = self.criterion(logits, y)
-        loss.backward()
-        self.optimizer.step()
+        if self.scaler is None:
+            loss.backward()
+            self.optimizer.step()
+        elif self.scaler._dev is not None:
+            self.scaler.eager_step(self.optimizer, loss)
+        else:
+            self.scaler.scale(loss).backward()
+            self.scaler.step(self.optimizer)
         self.eager_steps += 1
         self.logits = logits.detach()
         return loss.detach()
@@ -72,21 +80,30 @@ class GraphedTrainStep:
         self.host_ev = [None] * _RING
         self.stream = torch.cuda.Stream(dev)
         self.optimizer.begin_capture(self.hyper)
+        if self.scaler is not None:
+            self.scaler.begin_capture(self.optimizer, dev)
         self.optimizer.zero_grad(set_to_none=True)
         g = torch.cuda.CUDAGraph()
         drop0 = _ops._drop_counter[0]
         _ops.DROP_OFFSET_BASE[0] = self.drop_base
+        import loss as _loss_mod
+        _loss_mod.CAPTURE_SINK[0] = self.label_states = []
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         try:
             with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
                 logits = self.model(self.x)
                 loss = self.criterion(logits, self.y)
-                loss.backward()
-                self.optimizer.step()
+                if self.scaler is None:
+                    loss.backward()
+                    self.optimizer.step()
+                else:
+                    self.scaler.scale(loss).backward()
+                    self.scaler.step(self.optimizer)
                 self.loss = loss.detach()
                 self._static_logits = logits.detach()
         finally:
             _ops.DROP_OFFSET_BASE[0] = None
+            _loss_mod.CAPTURE_SINK[0] = None
         self.draws = _ops._drop_counter[0] - drop0      # Dropout3d draws of one step
         _ops._drop_counter[0] = drop0                   # nothing has been drawn yet: the first replay is this step
         self.drop_origin = drop0
@@ -116,6 +133,12 @@ class GraphedTrainStep:
         ev.record()
         self.host_ev[slot] = ev
         self.graph.replay()
+        if self.label_states:
+            # out-of-range labels raise F.one_hot's error for replays too (reference loss.py:27): the loss kernel's count
+            # rides to the pinned ring behind the replay and is checked at the caller's next read-back
+            import loss as _loss_mod
+            for st in self.label_states:
+                _loss_mod._note_label_flag(st)
         _ops._drop_counter[0] += self.draws
         _ops.WEIGHTS_EPOCH[0] += 1          # the replay's Adam wrote the parameters
         self.replays += 1
@@ -128,6 +151,8 @@ class GraphedTrainStep:
         allocated them), the workspace of the capture stream (_native._WS), the captured Adam launch plans, the static
         input / output buffers - the pool returns to the allocator only when all of them are gone."""
         self.optimizer.sync_captured_steps()
+        if self.scaler is not None and self.scaler._dev is not None:
+            self.scaler.end_capture()
         self.optimizer._captured = None
         for key in [k for k in self.optimizer._plans if k[1]]:       # (group, captured=True)
             del self.optimizer._plans[key]
@@ -142,7 +167,7 @@ class GraphedTrainStep:
                 del N._WS[key]
             _ops._PREPACK.clear()
             for name in ("x", "y", "loss", "logits", "_static_logits", "block", "drop_base", "hyper", "host", "host_ev",
-                         "stream"):
+                         "stream", "label_states"):
                 if hasattr(self, name):
                     delattr(self, name)
         self.graph = None

@@ -76,11 +76,18 @@ _pending = collections.deque()        # (event, pinned ring, slot) in launch ord
 _BAD_LABELS = "Class values must be smaller than num_classes."      # F.one_hot's message (reference loss.py:27)
 
 
+# graph.GraphedTrainStep sets this to a list while it captures a step: the state blocks of the captured loss calls, whose
+# counts it then reads back after every replay (a copy queued OUTSIDE the graph, into the same pinned ring)
+CAPTURE_SINK = [None]
+
+
 def _note_label_flag(state):
     """Queue the D2H copy of the forward kernel's out-of-range label count (4 bytes, stream-ordered, no sync)."""
     dev = state.device
     if torch.cuda.is_current_stream_capturing():
-        return          # a captured step reports bad labels through its NaN loss only
+        if CAPTURE_SINK[0] is not None:
+            CAPTURE_SINK[0].append(state)
+        return
     ent = _flag_host.get(dev)
     if ent is None:
         ent = _flag_host[dev] = [torch.zeros(_FLAG_RING, dtype=torch.int32).pin_memory(), 0, [None] * _FLAG_RING]

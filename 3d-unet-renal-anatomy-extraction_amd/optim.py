@@ -108,14 +108,22 @@ class Adam(torch.optim.Optimizer):
                 # gradients live at fixed addresses of the graph's memory pool)
                 plan["copied"] = None
                 self._captured["steps"][gi] = step_no - 1.0     # the first replay IS this step
-                check(N.lib.ru3d_adam_multi_dev(ptr(plan["table"]), ptr(plan["block_map"]), plan["nblocks"], _CHUNK,
-                                                ptr(self._captured["hyper"][gi]), stream()), "adam_multi_dev")
+                amp = self._captured.get("amp")
+                if amp is not None:
+                    # fp16: the device-side loss scaler decides (skip on overflow, 1 / scale, the true step number)
+                    self._captured["amp_base"][gi] = step_no - 1.0
+                    check(N.lib.ru3d_adam_multi_amp(ptr(plan["table"]), ptr(plan["block_map"]), plan["nblocks"], _CHUNK,
+                                                    ptr(self._captured["hyper"][gi]), ptr(amp), stream()), "adam_multi_amp")
+                else:
+                    check(N.lib.ru3d_adam_multi_dev(ptr(plan["table"]), ptr(plan["block_map"]), plan["nblocks"], _CHUNK,
+                                                    ptr(self._captured["hyper"][gi]), stream()), "adam_multi_dev")
                 continue
             ev = torch.cuda.Event()
             ev.record()
             plan["copied"] = ev
             if self._captured is not None and gi in self._captured["steps"]:
                 self._captured["steps"][gi] = step_no
+                self._captured["amp_base"][gi] = step_no      # (the scaler re-uploads its block with steps = 0)
             bc1 = 1.0 - b1 ** step_no
             bc2 = 1.0 - b2 ** step_no
             check(N.lib.ru3d_adam_multi(ptr(plan["table"]), ptr(plan["block_map"]), plan["nblocks"], _CHUNK,
@@ -131,7 +139,7 @@ class Adam(torch.optim.Optimizer):
         """hyper: device float32 [len(param_groups), 8]; the captured update kernels read their scalars from it."""
         if hyper.shape != (len(self.param_groups), 8) or hyper.dtype != torch.float32:
             raise ValueError("begin_capture: hyper must be float32 [groups, 8]")
-        self._captured = {"hyper": hyper, "steps": {}}
+        self._captured = {"hyper": hyper, "steps": {}, "amp": None, "amp_base": {}}
         for gi, group in enumerate(self.param_groups):       # device-side plan pieces cannot be made while capturing
             if group["params"]:
                 self._plan(gi, group, True)
@@ -150,6 +158,10 @@ class Adam(torch.optim.Optimizer):
             row[0] = group["lr"]; row[1] = b1; row[2] = b2; row[3] = group["eps"]
             row[4] = 1.0 - b1 ** step_no; row[5] = 1.0 - b2 ** step_no; row[6] = grad_scale
             row[7] = float(row[5]) ** 0.5     # sqrt of the float32 bias_corr2, as ru3d_adam_multi takes it on the host
+            if cap.get("amp") is not None:
+                # device-side loss scaler: the kernel derives the step number from the steps really taken (skips are
+                # decided on the device); slot 5 carries the count before the capture as an int32
+                row[5:6].view(torch.int32)[0] = int(cap["amp_base"].get(gi, 0.0))
 
     def sync_captured_steps(self):
         """Write the step counts reached by graph replays back into state[p]['step'] (state_dict fidelity)."""
@@ -157,6 +169,11 @@ class Adam(torch.optim.Optimizer):
         if cap is None or not cap.get("dirty"):
             return
         cap["dirty"] = False
+        if cap.get("amp") is not None:
+            # the device counted the steps that were not skipped (one 32-byte read-back, on demand only)
+            taken = int(cap["amp"].view(torch.int32)[5].item())
+            for gi in list(cap["steps"]):
+                cap["steps"][gi] = cap["amp_base"].get(gi, 0.0) + taken
         for gi, step_no in cap["steps"].items():
             for p in self.param_groups[gi]["params"]:
                 st = self.state.get(p)
@@ -179,7 +196,7 @@ class _GradTable:
         self.host = None
         self.copied = None
 
-    def update(self, params):
+    def update(self, params, capturing=False):
         grads = [p.grad for p in params]
         dev = next(g.device for g in grads if g is not None)
         key = tuple((0 if g is None else g.data_ptr(), p.numel()) for p, g in zip(params, grads))
@@ -203,8 +220,11 @@ class _GradTable:
                 raise N.Ru3dError("LossScaler: gradients must be contiguous float32")
             arr[i] = _AdamTensor(None, None if g is None else g.data_ptr(), None, None, p.numel())
         self.table.copy_(self.host, non_blocking=True)
-        self.copied = torch.cuda.Event()
-        self.copied.record()
+        if capturing:
+            self.copied = None          # the copy is a node of the graph; the pinned block stays as it is
+        else:
+            self.copied = torch.cuda.Event()
+            self.copied.record()
         self.key = key
 
 
@@ -232,6 +252,63 @@ class LossScaler:
         self._scale_t = None
         self._found = None
         self._tables = {}
+        self._dev = None            # captured mode: the ru3d_amp_state block (uint8[32]) on the device
+        self._dev_skipped = 0       # its `skipped` count at the last sync
+
+    # ---- captured mode (graph.GraphedTrainStep): the scaler state lives on the device, see ru3d_amp_state
+    def begin_capture(self, optimizer, device):
+        """Move the state into a device block and tell optim.Adam to take its decisions from there.  Call after
+        optimizer.begin_capture()."""
+        if not isinstance(optimizer, Adam) or optimizer._captured is None:
+            raise TypeError("LossScaler.begin_capture needs an optim.Adam that is being captured")
+        self._dev = torch.zeros(32, dtype=torch.uint8, device=device)
+        self._upload()
+        self._scale_t = self._dev[0:4].view(torch.float32).view(())
+        self._found = self._dev[8:12].view(torch.float32)
+        optimizer._captured["amp"] = self._dev
+
+    def _upload(self):
+        f = torch.zeros(8, dtype=torch.float32)
+        i = f.view(torch.int32)
+        f[0], f[1], f[2] = self.loss_scale, 1.0 / self.loss_scale, 0.0
+        i[3], i[4] = self.growth_tracker, 0
+        i[5] = 0
+        self._dev.copy_(f.view(torch.uint8))
+        self._dev_skipped = 0
+
+    def sync(self):
+        """Captured mode: read the device block back into the host-side fields (one 32-byte copy; state_dict, logging)."""
+        if self._dev is None:
+            return
+        f = self._dev.cpu().view(torch.float32)
+        i = f.view(torch.int32)
+        self.loss_scale = float(f[0])
+        self.growth_tracker = int(i[3])
+        self.skipped_steps += int(i[4]) - self._dev_skipped
+        self._dev_skipped = int(i[4])
+
+    def eager_step(self, optimizer, loss):
+        """One eager step (a batch of another shape) between replays: the state comes back to the host for it and returns
+        to the device block afterwards."""
+        dev = self._dev
+        self.sync()
+        optimizer.sync_captured_steps()
+        self._dev = None
+        self._scale_t = self._found = None
+        try:
+            self.scale(loss).backward()
+            return self.step(optimizer)
+        finally:
+            self._dev = dev
+            self._upload()
+            self._scale_t = dev[0:4].view(torch.float32).view(())
+            self._found = dev[8:12].view(torch.float32)
+
+    def end_capture(self):
+        self.sync()
+        self._dev = None
+        self._scale_t = None
+        self._found = None
 
     def scale(self, loss):
         if self._scale_t is None or self._scale_t.device != loss.device:
@@ -244,6 +321,24 @@ class LossScaler:
         if self._scale_t is None:
             raise RuntimeError("LossScaler.step() before LossScaler.scale(loss).backward()")
         fused = isinstance(optimizer, Adam)
+        if self._dev is not None:
+            if not torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("LossScaler: an eager step while the scaler is in captured mode (end_capture() first)")
+            # captured: check -> Adam (skips itself on overflow) -> scaler update, all decided on the device
+            for gi, group in enumerate(optimizer.param_groups):
+                params = [p for p in group["params"]]
+                if not any(p.grad is not None for p in params):
+                    continue
+                tab = self._tables.setdefault((id(optimizer), gi, "cap"), _GradTable())
+                tab.key = None
+                tab.update(params, capturing=True)
+                N.note_device(tab.table.device)
+                check(N.lib.ru3d_grad_scale_check(ptr(tab.table), ptr(tab.block_map), tab.nblocks, _CHUNK, 1.0,
+                                                  ptr(self._found), stream()), "grad_scale_check")
+            optimizer.step()
+            check(N.lib.ru3d_amp_update(ptr(self._dev), self.growth_factor, self.backoff_factor, self.growth_interval,
+                                        self.min_scale, self.max_scale, stream()), "amp_update")
+            return None
         inv = 1.0 / self.loss_scale
         self._found.zero_()
         any_grad = False
@@ -279,6 +374,7 @@ class LossScaler:
         {'loss_scaler0': {'loss_scale': float, 'unskipped': int}} - `unskipped` is apex's name for the count of clean
         steps since the last change of the scale.  The extra key 'ru3d' (skipped-step count, dtype tag) is ignored by
         apex's loader, which reads only the loss_scaler<i> entries."""
+        self.sync()
         return {"loss_scaler0": {"loss_scale": self.loss_scale, "unskipped": self.growth_tracker},
                 "ru3d": {"dtype": "fp16", "skipped_steps": self.skipped_steps}}
 

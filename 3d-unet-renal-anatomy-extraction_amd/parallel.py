@@ -137,7 +137,8 @@ def make_grad_sync(module, transport="rccl", process_group=None, **kwargs):
     if sync is None:
         kwargs.pop("grad_dtype", None)
         kwargs.pop("exchange", None)
-        sync = GradSync(module, transport="torch", process_group=process_group, **kwargs)
+        # explicit: GradSync would otherwise re-read RU3D_EXCHANGE and refuse rs_ag on the torch transport
+        sync = GradSync(module, transport="torch", process_group=process_group, exchange="allreduce", **kwargs)
     sync.fallback_reason = repr(err) if err is not None else None
     return sync
 
@@ -240,6 +241,10 @@ class GradSync:
         if self._fill_elems >= self.bucket_elems:
             self._launch()
 
+    def _in_buckets(self, t):
+        a = t.data_ptr()
+        return any(b.data_ptr() <= a < b.data_ptr() + 4 * b.numel() for b in self._buckets)
+
     def _flat(self, elems, like):
         i = self._bucket_idx
         self._bucket_idx += 1
@@ -275,7 +280,10 @@ class GradSync:
             v = flat[off:off + n].view_as(p.grad)
             if p.grad.data_ptr() != v.data_ptr():      # not born in place (first step, biases, a changed order)
                 views.append(v)
-                srcs.append(p.grad)
+                # a gradient that was born at LAST step's slot of some bucket while this step's order puts it elsewhere
+                # (a parameter frozen / unfrozen, a branch toggled): copying bucket -> bucket could run over a slot that
+                # is itself still a source - such sources are cloned before the first copy
+                srcs.append(p.grad.clone() if self._in_buckets(p.grad) else p.grad)
             layout.append((p, off, n))
             self._prev_layout[p.data_ptr()] = (idx, off, n)
             off += n

@@ -83,6 +83,31 @@ def _dist_ready():
         and torch.distributed.get_world_size() > 1
 
 
+class _RankShardSampler(torch.utils.data.Sampler):
+    """One process per GPU, one pass over the split per epoch: every epoch draws ONE permutation that is the same on all
+    ranks (seed + epoch counter) and this rank takes every world-th case of it, wrapped so that all ranks take the same
+    number of steps (the gradient exchange is collective).  The permutation changes with every __iter__, like the
+    reference's `shuffle=True` loader (trainer.py:543-547)."""
+
+    def __init__(self, n, rank, world, shuffle, seed, epoch=0):
+        self.n, self.rank, self.world, self.shuffle, self.seed, self.epoch = n, rank, world, shuffle, seed, epoch
+
+    def __len__(self):
+        return -(-self.n // self.world)
+
+    def __iter__(self):
+        if self.shuffle:
+            gen = torch.Generator()
+            gen.manual_seed((self.seed + 104729 * self.epoch) % (1 << 63))
+            order = torch.randperm(self.n, generator=gen).tolist()
+        else:
+            order = list(range(self.n))
+        self.epoch += 1
+        per_rank = len(self)
+        order = (order * (-(-per_rank * self.world // self.n)))[:per_rank * self.world]
+        return iter(order[self.rank::self.world])
+
+
 class Trainer():
     def __init__(self, model, optimizer, loss=None, dataset=None, batch_size=10,
                  dataloader_kwargs={'num_workers': 2, 'pin_memory': True},
@@ -180,7 +205,7 @@ class Trainer():
         return last
 
     def _graphed_step(self):
-        if self.capture_step is False or self._capture_failed or self._grad_sync is not None or self._scaler is not None:
+        if self.capture_step is False or self._capture_failed or self._grad_sync is not None:
             return None
         if self._graphed is None:
             import graph as graph_mod
@@ -195,8 +220,20 @@ class Trainer():
                 # that logs, counts, branches on values) must keep running every step
                 self._capture_failed = True
                 return None
-            self._graphed = graph_mod.GraphedTrainStep(self.model, self.loss, self.optimizer)
+            self._graphed = graph_mod.GraphedTrainStep(self.model, self.loss, self.optimizer, scaler=self._scaler)
         return self._graphed
+
+    def _release_graph(self):
+        """Drop the captured step: its graph holds raw pointers of the optimizer state / gradients it was captured with
+        and a private pool with a whole step's activations.  Called whenever those may change (load_checkpoint, a new
+        fit() - possibly with another storage type or loss scaler) and when fit() returns."""
+        if self._graphed is not None:
+            stats = getattr(self, "graph_stats", None) or {"replays": 0, "eager_steps": 0}
+            stats["replays"] += self._graphed.replays
+            stats["eager_steps"] += self._graphed.eager_steps
+            self.graph_stats = stats          # what the captured loop did, for logs and tests
+            self._graphed.release()
+            self._graphed = None
 
     def batch_loop(self, data_loader, is_train=True):
         results, pending = [], []
@@ -341,16 +378,9 @@ class Trainer():
         n = len(subset)
         if n == 0:
             return torch.utils.data.DataLoader(subset, shuffle=False, **kwargs)
-        if shuffle:
-            gen = torch.Generator()
-            gen.manual_seed(base % (1 << 63))                            # ONE permutation, the same on every rank
-            order = torch.randperm(n, generator=gen).tolist()
-        else:
-            order = list(range(n))
-        per_rank = -(-n // world)
-        order = (order * (-(-per_rank * world // n)))[:per_rank * world]  # wrap: equal step counts on all ranks
-        part = order[rank::world]
-        return torch.utils.data.DataLoader(torch.utils.data.Subset(subset, part), shuffle=False, **kwargs)
+        # a fresh common permutation per epoch (the loader is built once; the sampler counts its own epochs)
+        sampler = _RankShardSampler(n, rank, world, shuffle, torch.initial_seed(), self.current_epoch)
+        return torch.utils.data.DataLoader(subset, sampler=sampler, **kwargs)
 
     # ------------------------------------------------------------------ fit
     def fit(self, *args, num_epochs=None, save_dir=None, use_amp=False, opt_level='O1', **legacy):
@@ -392,6 +422,7 @@ class Trainer():
         if self.dataset is None:
             raise ValueError("Trainer.fit: no dataset (pass dataset= to Trainer or as the first fit() argument)")
 
+        self._release_graph()
         self.num_epochs = num_epochs
         self.use_amp = use_amp
         self.save_dir = save_dir
@@ -447,6 +478,7 @@ class Trainer():
             if save_dir is not None and save_last:
                 self.save_checkpoint(save_dir + '-last.pt')
         self.progress_bar.close()
+        self._release_graph()
         return self.best_result
 
     # ------------------------------------------------------------------ checkpoints
@@ -474,6 +506,7 @@ class Trainer():
             checkpoint = torch.load(file_path, map_location=self.device, weights_only=False)
         except TypeError:  # older torch without weights_only
             checkpoint = torch.load(file_path, map_location=self.device)
+        self._release_graph()       # optimizer.load_state_dict replaces the moment tensors a captured Adam points at
         self.model.load_state_dict(checkpoint['model_state_dict'])
         self.optimizer.load_state_dict(checkpoint['optimizer_state_dict'])
         self.current_epoch = checkpoint['current_epoch'] + 1

@@ -298,7 +298,7 @@ def main():
     # for bit (graph.py, tests/test_gpu_graph.py).  Round 2 measured the eager loop within 5 % of host-bound (17.5 ms of
     # enqueueing per 18.4 ms step); every kernel saving since then would otherwise disappear behind the interpreter.
     # The eager figure of the same steps rides along (`ms_per_step_eager`); `--launch eager` times that loop alone.
-    use_graph = args.launch in ("auto", "graph") and world == 1 and scaler is None and args.optimizer == "fused"
+    use_graph = args.launch in ("auto", "graph") and world == 1 and args.optimizer == "fused"
     gstep = None
 
     def fence():
@@ -309,7 +309,7 @@ def main():
     torch.cuda.reset_peak_memory_stats(dev)
     if use_graph:
         import graph as graph_mod
-        gstep = graph_mod.GraphedTrainStep(model, criterion, opt, warmup=max(1, args.warmup))
+        gstep = graph_mod.GraphedTrainStep(model, criterion, opt, warmup=max(1, args.warmup), scaler=scaler)
 
         def step():
             return gstep(x, y)
@@ -346,6 +346,9 @@ def main():
     if use_graph:
         # the same steps issued launch by launch, right behind the timed replays: the eager figure for comparison, and
         # the HIP-event timing of the roofline kernel (events recorded inside a captured graph cannot be read back)
+        if scaler is not None:
+            gstep.release()          # the loss scaler's state returns to the host for the eager steps
+            gstep = None
         if probe is not None:
             ops.set_probe(probe)
         fence()

@@ -361,6 +361,23 @@ int ru3d_adam_multi(const ru3d_adam_tensor* tensors, const int32_t* block_map, i
 int ru3d_adam_multi_dev(const ru3d_adam_tensor* tensors, const int32_t* block_map, int nblocks, int chunk_elems,
                         const float* hyper, void* stream);
 
+/* The loss scaler of fp16 training held on the DEVICE (32 bytes), so that a whole fp16 step - scaled loss, backward,
+ * overflow check, Adam, scaler update - is a fixed launch sequence a hipGraph can replay (the reference trains with apex
+ * O1: trainer.py:492-493, 538-542).  ru3d_grad_scale_check(scale = 1) writes found_inf; ru3d_adam_multi_amp is
+ * ru3d_adam_multi_dev that skips itself on found_inf != 0, multiplies the gradients by inv_scale and takes the Adam step
+ * number from hyper[5] (an int32 in the float slot: steps taken before the capture) + steps + 1; ru3d_amp_update then
+ * applies apex's schedule (overflow: scale *= backoff, tracker = 0, skipped++; clean: steps++, tracker++, after
+ * growth_interval clean steps scale *= growth) and clears found_inf.  The host reads the block back when it wants to
+ * know (state_dict, logging), not every step. */
+typedef struct ru3d_amp_state {
+    float scale, inv_scale, found_inf;
+    int32_t tracker, skipped, steps, reserved0, reserved1;
+} ru3d_amp_state;
+int ru3d_adam_multi_amp(const ru3d_adam_tensor* tensors, const int32_t* block_map, int nblocks, int chunk_elems,
+                        const float* hyper, const ru3d_amp_state* amp, void* stream);
+int ru3d_amp_update(ru3d_amp_state* amp, float growth_factor, float backoff_factor, int growth_interval, float min_scale,
+                    float max_scale, void* stream);
+
 /* conv3d input gradient FOLLOWED by the InstanceNorm + LeakyReLU backward of the tensor it differentiates (ResBlock
  * backward, network.py:411-416 read backwards: da = conv2^T(dy); dyn = d/dy1 of lrelu(IN(y1)) given da) - the
  * mirror image of ru3d_conv3d_fwd_in.  `act` = lrelu(IN(y1)) as the forward produced it, mean / scale = that

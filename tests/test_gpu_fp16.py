@@ -250,3 +250,52 @@ def test_loss_scaler_skips_on_overflow_and_grows(fused):
     sc2 = optim.LossScaler()
     sc2.load_state_dict(st)
     assert sc2.loss_scale == 4096.0
+
+
+def test_fp16_step_replays_from_a_graph_with_the_scaler_on_the_device():
+    """The reference's own training mode (apex O1: trainer.py:492-496, 538-542) as ONE captured hipGraph: the loss scaler's
+    state lives on the device (ru3d_amp_state), the update kernel skips itself on overflow, ru3d_amp_update applies apex's
+    schedule.  Trajectory against the eager LossScaler loop on the same batches: the same skips, the same scale, the same
+    step counts; weights equal up to the bias corrections' last bit (pow on the device vs on the host)."""
+    import graph
+
+    def setup():
+        torch.manual_seed(12)
+        model = network.ResUnet3D(2, 8, 1, 2).to(DEV).train()
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout3d):
+                m.p = 0.0
+        network.set_compute_dtype(model, H)
+        return model, optim.Adam(model.parameters(), lr=1e-3), L.HybirdLoss()
+
+    batches = [(O.synth_image((1, 1, 32, 32, 32), 40 + i).to(DEV), O.phantom_labels(1, (32, 32, 32), 2).to(DEV))
+               for i in range(9)]
+    # 2^30 overflows the fp16 gradients at first: a few skipped steps, halvings, then growth every 3 clean steps
+    kw = dict(init_scale=2.0 ** 30, growth_interval=3)
+    m_e, o_e, crit = setup()
+    sc_e = optim.LossScaler(**kw)
+    log_e = []
+    for x, y in batches:
+        o_e.zero_grad()
+        sc_e.scale(crit(m_e(x), y)).backward()
+        log_e.append(sc_e.step(o_e))
+    m_g, o_g, crit_g = setup()
+    sc_g = optim.LossScaler(**kw)
+    step = graph.GraphedTrainStep(m_g, crit_g, o_g, warmup=2, scaler=sc_g)
+    for x, y in batches:
+        step(x, y)
+    assert step.replays == len(batches) - 2
+    step.release()                                       # scaler and step counts come back to the host
+    assert sc_g._dev is None
+    assert log_e.count(False) >= 1                       # the scenario does contain skipped steps
+    assert sc_g.loss_scale == sc_e.loss_scale and sc_g.skipped_steps == sc_e.skipped_steps
+    assert sc_g.growth_tracker == sc_e.growth_tracker
+    for p_e, p_g in zip(m_e.parameters(), m_g.parameters()):
+        if p_e in o_e.state:
+            assert float(o_e.state[p_e]["step"]) == float(o_g.state[p_g]["step"]) == log_e.count(True)
+    for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, a.abs().max().item()), k
+    # and eager steps continue from there
+    o_g.zero_grad()
+    sc_g.scale(crit_g(m_g(batches[0][0]), batches[0][1])).backward()
+    assert sc_g.step(o_g) in (True, False)

@@ -217,8 +217,9 @@ def test_trainer_capture_step_equals_eager_fit():
     assert tr_e._graphed is None
     for capture in (True, None):          # None = the default: captured because optimizer and loss are this package's own
         tr_g, m_g = fit(capture)
-        assert tr_g._graphed is not None and tr_g._graphed.replays >= 3      # 3 epochs x (2 full batches + 1 short one)
-        assert tr_g._graphed.eager_steps >= 3
+        assert tr_g._graphed is None                      # fit() releases the graph and its private pool when it returns
+        assert tr_g.graph_stats["replays"] >= 3           # 3 epochs x (2 full batches + 1 short one)
+        assert tr_g.graph_stats["eager_steps"] >= 3
         assert tr_e.best_result == tr_g.best_result
         for (k, a), (_, b) in zip(m_e.state_dict().items(), m_g.state_dict().items()):
             assert torch.equal(a, b), k
@@ -256,3 +257,42 @@ def test_trainer_default_keeps_the_eager_loop_for_foreign_optimizer_or_loss():
                    batch_size=1, valid_split=0.0, dataloader_kwargs={"num_workers": 0}, progress=False)
     tr.fit(num_epochs=2)
     assert tr._graphed is None
+
+
+def test_fit_load_checkpoint_fit_recaptures(tmp_path):
+    """A captured step holds raw pointers of the optimizer state it was captured with: load_checkpoint
+    replaces the moment tensors, so the Trainer drops its graph there (and when fit() returns) and the next fit() captures
+    anew - the continued run equals the eager continuation bit for bit."""
+    import numpy as np
+    import trainer as T
+
+    class Cases(torch.utils.data.Dataset):
+        def __init__(self, n=6):
+            self.items = [{"image": O.synth_image((1, 1, 32, 32, 32), 900 + i)[0],
+                           "label": O.phantom_labels(1, (32, 32, 32), 3)[0]} for i in range(n)]
+
+        def __len__(self):
+            return len(self.items)
+
+        def __getitem__(self, i):
+            return self.items[i]
+
+    def run(capture):
+        torch.manual_seed(11)
+        np.random.seed(11)
+        model = network.ResUnet3D(2, 8, 1, 3).to(DEV)
+        tr = T.Trainer(model=model, optimizer=optim.Adam(model.parameters(), lr=1e-3), loss=L.HybirdLoss(),
+                       dataset=Cases(), batch_size=1, valid_split=0.0, dataloader_kwargs={"num_workers": 0},
+                       progress=False, capture_step=capture)
+        tr.fit(num_epochs=1, save_dir=str(tmp_path / ("c%d" % int(bool(capture)))), use_amp=True, opt_level="bf16")
+        assert tr._graphed is None                       # fit() leaves no graph (and no private pool) behind
+        tr.load_checkpoint(str(tmp_path / ("c%d" % int(bool(capture)))) + "-last.pt")
+        tr.fit(num_epochs=2, use_amp=True, opt_level="bf16")
+        return {k: v.detach().float().cpu() for k, v in model.state_dict().items()}, tr.optimizer.state_dict()
+
+    wa, sa = run(True)
+    wb, sb = run(False)
+    for k in wa:
+        assert torch.equal(wa[k], wb[k]), k
+    for (ia, pa), (ib, pb) in zip(sorted(sa["state"].items()), sorted(sb["state"].items())):
+        assert ia == ib and int(pa["step"]) == int(pb["step"]) and torch.equal(pa["exp_avg"].cpu(), pb["exp_avg"].cpu())

@@ -186,3 +186,29 @@ def test_fit_raises_on_out_of_range_labels():
     with pytest.raises(RuntimeError, match="Class values must be smaller than num_classes"):
         tr.fit(num_epochs=1)
     L.raise_on_bad_labels(wait=True)
+
+
+def test_fit_raises_on_out_of_range_labels_under_graph_replay():
+    """The same guarantee on the DEFAULT training path: with optim.Adam the step is captured and replayed, the
+    loss kernel's bad-label count is read back behind every replay and Trainer raises at its next read-back."""
+    class LateBad(Cases):
+        calls = 0
+
+        def __getitem__(self, i):
+            item = dict(super().__getitem__(i))
+            LateBad.calls += 1
+            if LateBad.calls >= 4:                   # steps 1-2 are the eager warm-up, step 3 the capture, 4.. replays
+                item["label"] = item["label"].clone()
+                item["label"][0, 0, 0] = 2           # the model has two classes
+            return item
+
+    model = _model()
+    L.raise_on_bad_labels(wait=True)
+    tr = T.Trainer(model=model, optimizer=optim.Adam(model.parameters(), lr=1e-4), loss=L.HybirdLoss(),
+                   dataset=LateBad(6), batch_size=1, valid_split=0.0, dataloader_kwargs={"num_workers": 0},
+                   sync_every=1, progress=False)
+    with pytest.raises(RuntimeError, match="Class values must be smaller than num_classes"):
+        tr.fit(num_epochs=1)
+    assert tr._graphed is not None and tr._graphed.replays >= 2      # the step that raised was a replay
+    L.raise_on_bad_labels(wait=True)
+    tr._release_graph()

@@ -372,3 +372,25 @@ def test_graphed_step_needs_the_fused_optimizer():
     m = torch.nn.Linear(2, 2)
     with pytest.raises(TypeError):
         graph.GraphedTrainStep(m, torch.nn.MSELoss(), torch.optim.Adam(m.parameters()))
+
+
+def test_rank_shard_sampler_reshuffles_every_epoch_and_covers_the_split():
+    """Multi-rank training without num_samples: the loader is built once, so the sampler itself must draw a new
+    common permutation per epoch (the reference's shuffle=True loader, trainer.py:543-547); every epoch the ranks' shards
+    together cover the split, with equal step counts."""
+    import trainer as T
+    n, world = 11, 3
+    samplers = [T._RankShardSampler(n, r, world, True, seed=1234, epoch=0) for r in range(world)]
+    epochs = []
+    for _ in range(3):
+        shards = [list(s) for s in samplers]
+        assert len({len(sh) for sh in shards}) == 1 and len(shards[0]) == len(samplers[0]) == 4
+        assert set(i for sh in shards for i in sh) == set(range(n))      # wrapped to 12 draws: one case twice
+        epochs.append(shards)
+    assert epochs[0][0] != epochs[1][0] and epochs[1][0] != epochs[2][0]   # a rank sees a new order every epoch
+    # a resumed run (epoch counter from the checkpoint) continues the sequence
+    resumed = T._RankShardSampler(n, 0, world, True, seed=1234, epoch=2)
+    assert list(resumed) == epochs[2][0]
+    # shuffle=False (validation): the same contiguous deal every epoch
+    v = T._RankShardSampler(n, 1, world, False, seed=0)
+    assert list(v) == list(v) == [1, 4, 7, 10]
