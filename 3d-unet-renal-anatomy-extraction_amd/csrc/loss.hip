@@ -512,7 +512,10 @@ __global__ __launch_bounds__(256) void adam_multi_amp_kernel(const ru3d_adam_ten
                                                              const ru3d_amp_state* __restrict__ amp) {
     if (amp->found_inf != 0.f) return;                                   // overflow: the step is skipped
     const int t = __float_as_int(hyper[5]) + amp->steps + 1;             // Adam step number of this update
-    const double bc1 = 1.0 - pow((double)hyper[1], (double)t), bc2 = 1.0 - pow((double)hyper[2], (double)t);
+    // the betas in double (float value + residual in the slots the captured amp launch does not use otherwise): the bias
+    // corrections then equal the host's `1 - beta ** t` to the last bit or two
+    const double b1d = (double)hyper[1] + (double)hyper[4], b2d = (double)hyper[2] + (double)hyper[7];
+    const double bc1 = 1.0 - pow(b1d, (double)t), bc2 = 1.0 - pow(b2d, (double)t);
     adam_multi_body(tensors, block_map, chunk_elems, hyper[0], hyper[1], hyper[2], hyper[3], (float)bc1, sqrtf((float)bc2),
                     amp->inv_scale);
 }

@@ -53,15 +53,18 @@ class GraphedTrainStep:
         self.optimizer.zero_grad(set_to_none=True)
         logits = self.model(x)
         loss = self.criterion(logits, y)
+        stepped = True
         if self.scaler is None:
             loss.backward()
             self.optimizer.step()
         elif self.scaler._dev is not None:
-            self.scaler.eager_step(self.optimizer, loss)
+            stepped = self.scaler.eager_step(self.optimizer, loss)
         else:
             self.scaler.scale(loss).backward()
-            self.scaler.step(self.optimizer)
-        self.eager_steps += 1
+            stepped = self.scaler.step(self.optimizer)
+        # a step the loss scaler skipped (overflow) created no Adam state: it does not count as warm-up
+        self.eager_steps += 1 if (stepped or self.graph is not None) else 0
+        self.skipped_warmup = getattr(self, "skipped_warmup", 0) + (0 if stepped else 1)
         self.logits = logits.detach()
         return loss.detach()
 

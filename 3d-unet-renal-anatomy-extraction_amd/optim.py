@@ -162,6 +162,8 @@ class Adam(torch.optim.Optimizer):
                 # device-side loss scaler: the kernel derives the step number from the steps really taken (skips are
                 # decided on the device); slot 5 carries the count before the capture as an int32
                 row[5:6].view(torch.int32)[0] = int(cap["amp_base"].get(gi, 0.0))
+                row[4] = b1 - float(torch.tensor(b1, dtype=torch.float32))      # residuals: beta = float32 value + this
+                row[7] = b2 - float(torch.tensor(b2, dtype=torch.float32))
 
     def sync_captured_steps(self):
         """Write the step counts reached by graph replays back into state[p]['step'] (state_dict fidelity)."""
@@ -184,6 +186,14 @@ class Adam(torch.optim.Optimizer):
         self.sync_captured_steps()
         return super().state_dict()
 
+    def load_state_dict(self, state_dict):
+        """torch's layout; the step counts are kept on the HOST whatever device the checkpoint was mapped to (step() reads
+        them every call: a device tensor there is a sync per step and cannot be read inside a graph capture)."""
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            if torch.is_tensor(st.get("step")) and st["step"].device.type != "cpu":
+                st["step"] = st["step"].detach().to("cpu", torch.float32)
+
 
 class _GradTable:
     """Device table of (grad pointer, count) per parameter in ru3d_adam_tensor layout + block map, rebuilt when the
@@ -196,6 +206,22 @@ class _GradTable:
         self.host = None
         self.copied = None
 
+    def prepare(self, params, dev):
+        """The allocations (pinned host block, device table, block map): not allowed while a stream is capturing, so a
+        captured step calls this beforehand (LossScaler.begin_capture)."""
+        n = len(params)
+        if self.host is not None and self.host.numel() == n * ctypes.sizeof(_AdamTensor):
+            return
+        self.host = torch.empty(n * ctypes.sizeof(_AdamTensor), dtype=torch.uint8).pin_memory()
+        self.table = torch.empty(self.host.numel(), dtype=torch.uint8, device=dev)
+        blocks = []
+        for ti, p in enumerate(params):
+            for c in range((p.numel() + _CHUNK - 1) // _CHUNK):
+                blocks += [ti, c]
+        self.block_map = torch.tensor(blocks, dtype=torch.int32).to(dev)
+        self.nblocks = len(blocks) // 2
+        self.key = None
+
     def update(self, params, capturing=False):
         grads = [p.grad for p in params]
         dev = next(g.device for g in grads if g is not None)
@@ -205,15 +231,7 @@ class _GradTable:
         if self.copied is not None:
             self.copied.synchronize()
         n = len(params)
-        if self.host is None or self.host.numel() != n * ctypes.sizeof(_AdamTensor):
-            self.host = torch.empty(n * ctypes.sizeof(_AdamTensor), dtype=torch.uint8).pin_memory()
-            self.table = torch.empty(self.host.numel(), dtype=torch.uint8, device=dev)
-            blocks = []
-            for ti, p in enumerate(params):
-                for c in range((p.numel() + _CHUNK - 1) // _CHUNK):
-                    blocks += [ti, c]
-            self.block_map = torch.tensor(blocks, dtype=torch.int32).to(dev)
-            self.nblocks = len(blocks) // 2
+        self.prepare(params, dev)
         arr = (_AdamTensor * n).from_buffer(self.host.numpy())
         for i, (p, g) in enumerate(zip(params, grads)):
             if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
@@ -263,6 +281,9 @@ class LossScaler:
             raise TypeError("LossScaler.begin_capture needs an optim.Adam that is being captured")
         self._dev = torch.zeros(32, dtype=torch.uint8, device=device)
         self._upload()
+        for gi, group in enumerate(optimizer.param_groups):
+            if group["params"]:
+                self._tables.setdefault((id(optimizer), gi, "cap"), _GradTable()).prepare(list(group["params"]), device)
         self._scale_t = self._dev[0:4].view(torch.float32).view(())
         self._found = self._dev[8:12].view(torch.float32)
         optimizer._captured["amp"] = self._dev

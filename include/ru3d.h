@@ -365,7 +365,8 @@ int ru3d_adam_multi_dev(const ru3d_adam_tensor* tensors, const int32_t* block_ma
  * overflow check, Adam, scaler update - is a fixed launch sequence a hipGraph can replay (the reference trains with apex
  * O1: trainer.py:492-493, 538-542).  ru3d_grad_scale_check(scale = 1) writes found_inf; ru3d_adam_multi_amp is
  * ru3d_adam_multi_dev that skips itself on found_inf != 0, multiplies the gradients by inv_scale and takes the Adam step
- * number from hyper[5] (an int32 in the float slot: steps taken before the capture) + steps + 1; ru3d_amp_update then
+ * number from hyper[5] (an int32 in the float slot: steps taken before the capture) + steps + 1, with hyper[4] / hyper[7]
+ * the residuals beta - (float)beta of the two betas (bias corrections in double); ru3d_amp_update then
  * applies apex's schedule (overflow: scale *= backoff, tracker = 0, skipped++; clean: steps++, tracker++, after
  * growth_interval clean steps scale *= growth) and clears found_inf.  The host reads the block back when it wants to
  * know (state_dict, logging), not every step. */

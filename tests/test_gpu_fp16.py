@@ -269,7 +269,7 @@ def test_fp16_step_replays_from_a_graph_with_the_scaler_on_the_device():
         return model, optim.Adam(model.parameters(), lr=1e-3), L.HybirdLoss()
 
     batches = [(O.synth_image((1, 1, 32, 32, 32), 40 + i).to(DEV), O.phantom_labels(1, (32, 32, 32), 2).to(DEV))
-               for i in range(9)]
+               for i in range(16)]
     # 2^30 overflows the fp16 gradients at first: a few skipped steps, halvings, then growth every 3 clean steps
     kw = dict(init_scale=2.0 ** 30, growth_interval=3)
     m_e, o_e, crit = setup()
@@ -284,7 +284,7 @@ def test_fp16_step_replays_from_a_graph_with_the_scaler_on_the_device():
     step = graph.GraphedTrainStep(m_g, crit_g, o_g, warmup=2, scaler=sc_g)
     for x, y in batches:
         step(x, y)
-    assert step.replays == len(batches) - 2
+    assert step.replays >= 3 and step.replays + step.eager_steps + step.skipped_warmup == len(batches)
     step.release()                                       # scaler and step counts come back to the host
     assert sc_g._dev is None
     assert log_e.count(False) >= 1                       # the scenario does contain skipped steps
