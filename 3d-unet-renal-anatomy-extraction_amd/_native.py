@@ -137,6 +137,7 @@ SIGNATURES = {
     "ru3d_comm_destroy": (_i, [_vp]),
     "ru3d_probe_begin": (_i, [_i, _i, _i, _i, _i, _i]),
     "ru3d_probe_end": (_i, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)]),
+    "ru3d_set_cu_budget_device": (_i, [_i, _i]),
     "ru3d_set_cu_budget": (_i, [_i]),
     "ru3d_get_cu_budget": (_i, []),
     "ru3d_flat_cast": (_i, [_vp, _i, _vp, _i, _i64, _f, _vp]),

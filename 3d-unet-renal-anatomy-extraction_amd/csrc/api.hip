@@ -304,9 +304,6 @@ extern "C" int ru3d_conv3d_fwd_in(const ru3d_tensor* x, const void* w_packed, co
     if (fwd_in_fused(x, y, k, stride, dtype)) {
         RU3D_REQUIRE(x->n == y->n && y->d == x->d && y->h == x->h && y->w == x->w, "conv3d_fwd_in: extents mismatch");
         const ConvGeom g = fwd_geom(x, y, k, stride);
-        const size_t slab = mfma_conv_stats_slab_bytes(g);
-        hipError_t e = hipMemsetAsync(ws, 0, slab, as_stream(stream));   // workgroups that never touch a sample add 0
-        if (e != hipSuccess) return ru3d_fail((int)e, "conv3d_fwd_in: memset failed: %s", hipGetErrorString(e));
         int rc = conv_mfma_launch(x->ptr, w_packed, bias, nullptr, y->ptr, g, as_stream(stream), (float*)ws);
         if (rc) return rc;
         return mfma_conv_stats_finalize(g, (const float*)ws, drop_scale, eps, mean, scale, as_stream(stream));
@@ -481,8 +478,6 @@ extern "C" int ru3d_conv3d_s2_pair_fwd_in(const ru3d_tensor* x, const void* w3_p
     const ConvGeom g = fwd_geom(x, y3, 3, 2);
     const size_t slab = conv_s2_tile_slab_bytes(g);
     RU3D_REQUIRE(ws_bytes >= slab, "conv3d_s2_pair_fwd_in: workspace too small");
-    hipError_t e = hipMemsetAsync(ws, 0, slab, as_stream(stream));
-    if (e != hipSuccess) return ru3d_fail((int)e, "conv3d_s2_pair_fwd_in: memset failed: %s", hipGetErrorString(e));
     int rc = conv_s2_tile_launch(x->ptr, w3_packed, b3, y3->ptr, g, (float*)ws, w1_packed, b1, y1->ptr, y1->ld, as_stream(stream));
     if (rc) return rc;
     int gx, cb;
@@ -579,8 +574,6 @@ extern "C" int ru3d_conv3d_dgrad_in_bwd(const ru3d_tensor* dy, const void* w_pac
         const ConvGeom g = dgrad_s1_geom(dy, da, k);
         const size_t slab = (mfma_conv_stats_slab_bytes(g) + 255) / 256 * 256;
         float* m12 = (float*)((char*)ws + slab);
-        hipError_t e = hipMemsetAsync(ws, 0, slab, as_stream(stream));   // workgroups that never touch a sample add 0
-        if (e != hipSuccess) return ru3d_fail((int)e, "conv3d_dgrad_in_bwd: memset failed: %s", hipGetErrorString(e));
         int rc = conv_mfma_launch(dy->ptr, w_packed, nullptr, nullptr, da->ptr, g, as_stream(stream), (float*)ws, nullptr, 0,
                                   act->ptr, act->ld, slope);
         if (rc) return rc;
@@ -762,9 +755,6 @@ extern "C" int ru3d_convtranspose3d_k3s2p1_fwd_in(const ru3d_tensor* x, const vo
                  "convtranspose3d_fwd_in: workspace too small");
     if (convt_fwd_in_fused(x, y, dtype)) {
         const ConvGeom g = convt_fwd_geom(x, y);
-        const size_t slab = convt_s2_tile_slab_bytes(g);
-        hipError_t e = hipMemsetAsync(ws, 0, slab, as_stream(stream));   // (workgroup, wave, sample) triples that never meet add 0
-        if (e != hipSuccess) return ru3d_fail((int)e, "convtranspose3d_fwd_in: memset failed: %s", hipGetErrorString(e));
         int rc = convt_s2_tile_launch(x->ptr, w_packed, bias, nullptr, y->ptr, g, (float*)ws, nullptr, 0, nullptr, as_stream(stream));
         if (rc) return rc;
         int gx, cb;

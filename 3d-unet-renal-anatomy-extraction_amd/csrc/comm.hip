@@ -228,13 +228,30 @@ extern "C" int ru3d_comm_available(void) {
 }
 
 // ---------------------------------------------------------------- CU budget of the persistent kernels
-static int g_cu_budget = 0;
-extern "C" int ru3d_set_cu_budget(int cus) {
-    RU3D_REQUIRE(cus >= 0 && cus <= 1024, "set_cu_budget: %d", cus);
-    g_cu_budget = cus;
+// A property of the DEVICE, not of the process: how many of a device's CUs the persistent one-workgroup-per-CU kernels
+// launched on it may occupy (the rest is left to RCCL's reduction kernels on the side stream).  Two models on two devices
+// of one process have two budgets; two models on one device share that device's CUs and therefore its budget.  The
+// entry points look the value up for the device their stream belongs to (Ru3dDeviceGuard makes it current).
+#define RU3D_MAX_DEVICES 64
+static int g_cu_budget[RU3D_MAX_DEVICES];
+static int current_device_index() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        dev = 0;
+    }
+    return (dev >= 0 && dev < RU3D_MAX_DEVICES) ? dev : 0;
+}
+extern "C" int ru3d_set_cu_budget_device(int device, int cus) {
+    RU3D_REQUIRE(cus >= 0 && cus <= 1024 && device >= 0 && device < RU3D_MAX_DEVICES, "set_cu_budget: device %d, %d CUs", device, cus);
+    g_cu_budget[device] = cus;
     return 0;
 }
-extern "C" int ru3d_get_cu_budget(void) { return g_cu_budget > 0 ? g_cu_budget : 256; }
+extern "C" int ru3d_set_cu_budget(int cus) { return ru3d_set_cu_budget_device(current_device_index(), cus); }
+extern "C" int ru3d_get_cu_budget(void) {
+    const int b = g_cu_budget[current_device_index()];
+    return b > 0 ? b : 256;
+}
 
 // ---------------------------------------------------------------- kernel probe (bench.py's roofline figure)
 // HIP-event pairs recorded by the LIBRARY on the launch stream, right around the main kernel of every 3x3x3 stride-1

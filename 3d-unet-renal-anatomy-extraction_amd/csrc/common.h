@@ -136,6 +136,15 @@ __device__ __forceinline__ void store_vec(T* p, const float (&in)[VEC]) {
     *reinterpret_cast<VT*>(p) = x;
 }
 
+// Statistics slabs (slab[(workgroup * 4 + wave)][n][cb][2] floats): a wave writes only the rows of the samples it meets, the
+// fixed-order finalize reads every row.  Each wave clears its own N rows when the kernel starts (1 KB of stores, same
+// wave -> program order with its later writes) - the callers' hipMemsetAsync per conv launch (23 a step, 5 us each) is gone.
+__device__ __forceinline__ void ru3d_clear_own_slab_rows(float* slab, int64_t wave_row, int N, int row_floats) {
+    float* base = slab + wave_row * (int64_t)N * row_floats;
+    for (int i = threadIdx.x & 63; i < N * row_floats; i += 64) base[i] = 0.f;
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): the zeros have left this wave before anything else does
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

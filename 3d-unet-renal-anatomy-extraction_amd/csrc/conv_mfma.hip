@@ -74,8 +74,6 @@ struct MfmaConvArgs {
     void* ws;              // caller-owned workspace for the split-K partials (may be null: no split-K)
     size_t ws_bytes;
     int* defer_ks;         // host side: leave the split-K partials in ws un-summed and report their count here (0 = y is final)
-    int xcd_cout;          // conv3_s1_mfma_kernel: 1-D launch, every XCD owns a fixed slice of the cout tiles (gy = tiles)
-    int gy, gz;            // cout tiles / split-K slices of that decomposition
 };
 
 // T1 (bijective): consecutive hardware block ids round-robin over the 8 XCDs; give each XCD a contiguous
@@ -101,21 +99,12 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
     __shared__ __attribute__((aligned(16))) bf16 lds[HV * MF_PITCH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // Deep levels (hundreds of channels on 8^3 / 16^3 voxels): the weights are the big operand.  Hardware workgroup ids
-    // go round-robin over the 8 XCDs, so with `xcd_cout` the launch is 1-D and XCD k takes the cout tiles
-    // [k * gy / 8, (k + 1) * gy / 8) for ALL voxel tiles and split-K slices: its L2 (4 MiB) holds 1/8 of the weight
-    // (1.8 MB of 14 MB at 512 -> 512) and every weight byte leaves HBM once instead of once per voxel tile.
-    int by = blockIdx.y, bz = blockIdx.z, gz = gridDim.z, tile;
-    if (a.xcd_cout) {
-        const int l = blockIdx.x, per = a.gy >> 3, slot = l >> 3;
-        by = (l & 7) * per + slot % per;
-        const int rest = slot / per;
-        tile = rest % a.nblk;
-        bz = rest / a.nblk;
-        gz = a.gz;
-    } else {
-        tile = xcd_remap(blockIdx.x, a.nblk);
-    }
+    // (round 4: a 1-D launch in which every XCD owned a fixed slice of the cout tiles - its L2 holding 1/8 of the weight,
+    // every weight byte leaving HBM once - changed nothing: 28.2 vs 28.4 us at 512 -> 512 on 8^3, 37.9 vs 37.9 at 16^3,
+    // profiles/r04_deep_level_convs.txt.  Where the weight bytes are served from is not what bounds these kernels; the
+    // CUs' L1 path is: four waves x 1 KB of weight fragments per 2 MFMAs.)
+    const int by = blockIdx.y, bz = blockIdx.z, gz = gridDim.z;
+    int tile = xcd_remap(blockIdx.x, a.nblk);
     const int tw_i = tile % a.tiles_w;
     tile /= a.tiles_w;
     const int th_i = tile % a.tiles_h;
@@ -399,6 +388,8 @@ __global__ __launch_bounds__(512, 2) void conv3_s1_pc_kernel(MfmaConvArgs a) {
     // fused InstanceNorm statistics: running {sum, sum^2} of this wave's stored values for the sample `cur_n`
     float st1[NT][8], st2[NT][8];
     int cur_n = -1;
+    if (a.stat_slab)
+        ru3d_clear_own_slab_rows(a.stat_slab, (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave, a.N, NT * 32 * 2);
     auto stat_flush = [&]() {
         if (!a.stat_slab || cur_n < 0) return;
         const int blk = blockIdx.y * gridDim.x + blockIdx.x;
@@ -608,14 +599,7 @@ static int launch_s1(const MfmaConvArgs& a0, bool nt2, hipStream_t st) {
     if (nblk > 0x7fffffff) return ru3d_fail(-1, "conv_mfma: grid too large");
     a.nblk = (int)nblk;
     const int ks = a.part ? a.ksplit : 1;
-    // RU3D_CONV_XCD: 0 = (tile, cout, split) grid; 1 (default) = XCD-owned cout slices where the weight is the large
-    // operand (split-K shapes); 2 = on every shape of this kernel with a multiple of 8 cout tiles
-    static const int xcd_mode = getenv("RU3D_CONV_XCD") ? atoi(getenv("RU3D_CONV_XCD")) : 1;
-    a.gy = a.Cout / (nt2 ? 64 : 32);
-    a.gz = ks;
-    a.xcd_cout = (xcd_mode == 2 || (xcd_mode == 1 && ks > 1)) && (a.gy % 8) == 0 && nblk * a.gy * ks < 0x7fffffff;
-    dim3 grid((unsigned)nblk, a.gy, ks);
-    if (a.xcd_cout) grid = dim3((unsigned)(nblk * a.gy * ks), 1, 1);
+    dim3 grid((unsigned)nblk, a.Cout / (nt2 ? 64 : 32), ks);
     if (nt2) {
         hipLaunchKernelGGL((conv3_s1_mfma_kernel<TD, TH, TW, MT, 2>), grid, dim3(256), 0, st, a);
     } else {
@@ -675,13 +659,12 @@ static S1Plan s1_plan(int N, int D, int H, int W, int Cout) {
 
 // split-K factor of the deepest level (0/1 = none): the 256-voxel x 32-cout decomposition leaves CUs idle
 static int s1_ksplit(const S1Plan& p, int N, int D, int H, int W, int Cin, int Cout) {
-    static const int ksplit_mode = getenv("RU3D_CONV_KSPLIT") ? atoi(getenv("RU3D_CONV_KSPLIT")) : 1;
     const int64_t units = p.nblk_pc * (Cout / 32);
     const int nchunks = Cin / 32;
-    // mode 2: aim at two workgroups per CU (the kernel stages, then computes: a second resident workgroup's MFMAs
-    // cover the first one's staging)
-    const int64_t target = (ksplit_mode == 2 || (ksplit_mode == 3 && units >= 256)) ? 512 : 256;   // 3: level-3-like shapes only
-    if (!ksplit_mode || !p.small || p.nt2 || units >= target || nchunks < 2) return 1;
+    // one workgroup per CU is the aim: splitting further (two resident workgroups per CU) measured slower in round 3
+    // (16^3: 38.8 -> 43.1 us, 8^3: 26.8 -> 28.2 us) - these kernels are bound by what enters the CU, not by its occupancy
+    const int64_t target = 256;
+    if (!p.small || p.nt2 || units >= target || nchunks < 2) return 1;
     int ks = 2;
     while (ks * 2 <= nchunks && units * ks < target) ks *= 2;
     (void)N; (void)D; (void)H; (void)W;
@@ -1583,8 +1566,7 @@ static int launch_direct(const void* x, const void* w, const float* bias, const 
         return convt_s2_tile_launch(x, w, bias, res, y, g, nullptr, nullptr, 0, nullptr, st);
     if (!g.transposed && !res && conv_s2_tile_eligible(g) && (((uintptr_t)x) % 16) == 0 && (((uintptr_t)y) % 8) == 0)
         return conv_s2_tile_launch(x, w, bias, y, g, nullptr, nullptr, nullptr, nullptr, 0, st);
-    static const int ksplit_mode = getenv("RU3D_CONV_KSPLIT") ? atoi(getenv("RU3D_CONV_KSPLIT")) : 1;
-    if (ksplit_mode && nblk * (g.Cout / (nt2 ? 64 : 32)) < 384) {
+    if (nblk * (g.Cout / (nt2 ? 64 : 32)) < 384) {
         // few, long workgroups: split the reduction over the waves of 32-voxel workgroups instead
         const int64_t tiles = (a.total + 31) / 32;
         dim3 gk((unsigned)tiles, g.Cout / (nt2 ? 64 : 32), g.transposed ? 8 : 1);
@@ -1603,8 +1585,7 @@ static int launch_direct(const void* x, const void* w, const float* bias, const 
         if (a.hw >= 24 && g.Cin <= 128) {
             // one cout tile: 256 positions per workgroup (8 column tiles per weight fragment) - the 110 KB of weights a
             // workgroup pulls through its CU's ~10 B/clk are the larger part of what enters it
-            static const int big = getenv("RU3D_CONVT_BIG") ? atoi(getenv("RU3D_CONVT_BIG")) : 1;
-            if (!nt2 && big && g.Cin <= 64 && a.hh >= 4) return launch_convt_tile<1, 2, 4, 32>(a, g.N, st);
+            if (!nt2 && g.Cin <= 64 && a.hh >= 4) return launch_convt_tile<1, 2, 4, 32>(a, g.N, st);
             return nt2 ? launch_convt_tile<2, 2, 2, 32>(a, g.N, st) : launch_convt_tile<1, 2, 2, 32>(a, g.N, st);
         }
         if (a.hw >= 12 && g.Cin <= 256) {
@@ -1612,19 +1593,14 @@ static int launch_direct(const void* x, const void* w, const float* bias, const 
         }
     }
     dim3 grid((unsigned)nblk, g.Cout / (nt2 ? 64 : 32));
-    static const int gather_mode = getenv("RU3D_CONV_GATHER") ? atoi(getenv("RU3D_CONV_GATHER")) : 1;
-    if (gather_mode && !g.transposed && g.k * g.k * g.k <= 27) {
+    if (!g.transposed && g.k * g.k * g.k <= 27) {
         if (nt2) hipLaunchKernelGGL((conv_gather_mfma_kernel<2>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((conv_gather_mfma_kernel<1>), grid, dim3(256), 0, st, a);
         return ru3d_check_launch("conv_gather_mfma");
     }
-    if (g.transposed) {
-        if (nt2) hipLaunchKernelGGL((conv_direct_mfma_kernel<2, true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((conv_direct_mfma_kernel<1, true>), grid, dim3(256), 0, st, a);
-    } else {
-        if (nt2) hipLaunchKernelGGL((conv_direct_mfma_kernel<2, false>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((conv_direct_mfma_kernel<1, false>), grid, dim3(256), 0, st, a);
-    }
+    if (!g.transposed) return ru3d_fail(-1, "conv_direct_mfma: no gather kernel for k = %d", g.k);
+    if (nt2) hipLaunchKernelGGL((conv_direct_mfma_kernel<2, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_direct_mfma_kernel<1, true>), grid, dim3(256), 0, st, a);
     return ru3d_check_launch("conv_direct_mfma");
 }
 
@@ -1723,8 +1699,6 @@ static int conv_mfma_launch_inner(const void* x, const void* w, const float* bia
     a.stat_slab = stat_slab;
     a.part = nullptr;
     a.ksplit = 1;
-    a.xcd_cout = 0;
-    a.gy = a.gz = 1;
     a.defer_ks = (res || stat_slab) ? nullptr : defer_ks;
     a.ws = ws;
     a.ws_bytes = ws_bytes;
@@ -2091,8 +2065,7 @@ static int wgrad_mfma_groups(const WgradGeom& g) {
     wgrad_tiles(g, &td, &th, &tw);
     const int64_t ntiles = (int64_t)g.N * ((g.Do + td - 1) / td) * ((g.Ho + th - 1) / th) * ((g.Wo + tw - 1) / tw);
     const int pairs = (g.Cin / 32) * (g.Cout / 32);
-    static const int wg_blocks = getenv("RU3D_WGRAD_BLOCKS") ? atoi(getenv("RU3D_WGRAD_BLOCKS")) : 512;
-    int64_t G = wg_blocks / pairs;
+    int64_t G = 512 / pairs;      // 512 workgroups in all: the tuned optimum (256 / 384 / 768 all slower, round 3)
     if (G < 1) G = 1;
     if (G > ntiles) G = ntiles;
     // one workgroup per CU already and few tiles each (512 -> 512 on 8^3: 256 pairs x 4 tiles): a single workgroup per

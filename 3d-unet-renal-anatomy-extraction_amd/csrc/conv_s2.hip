@@ -196,6 +196,7 @@ __device__ __forceinline__ void t_consumer(const S2Args& a, const char* lds, con
 #pragma unroll
     for (int i = 0; i < 8; i++) st1[i] = st2[i] = 0.f;
     int cur_n = -1;
+    if (HAS_STATS) ru3d_clear_own_slab_rows(a.stat_slab, (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + WV, a.N, 32 * 2);
     auto stat_flush = [&]() {
         if (!HAS_STATS || cur_n < 0) return;
         float* dst = a.stat_slab + ((((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + WV) * a.N + cur_n) * 32) * 2;
@@ -207,7 +208,7 @@ __device__ __forceinline__ void t_consumer(const S2Args& a, const char* lds, con
                 s1 += __shfl_xor(s1, o, 64);
                 s2 += __shfl_xor(s2, o, 64);
             }
-            if (p == 0) {      // += : the XCD-wise deal of units can bring a workgroup back to a sample (the slab starts at 0)
+            if (p == 0) {      // += : the XCD-wise deal of units can bring a workgroup back to a sample (the wave cleared its rows when the kernel started)
                 dst[(8 * g4 + i) * 2] += s1;
                 dst[(8 * g4 + i) * 2 + 1] += s2;
             }
@@ -561,6 +562,7 @@ __device__ __forceinline__ void g_consumer(const S2Args& a, const char* lds, int
 #pragma unroll
     for (int i = 0; i < 4; i++) st1[i] = st2[i] = 0.f;
     int cur_n = -1;
+    if (HAS_STATS) ru3d_clear_own_slab_rows(a.stat_slab, (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave, a.N, 64 * 2);
     auto stat_flush = [&]() {
         if (!HAS_STATS || cur_n < 0) return;
         float* dst = a.stat_slab + ((((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * a.N + cur_n) * 64) * 2;

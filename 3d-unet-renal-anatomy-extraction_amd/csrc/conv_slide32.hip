@@ -176,6 +176,8 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide32_kernel(Slide32Args a)
 #pragma unroll
     for (int i = 0; i < 8; i++) st1[i] = st2[i] = 0.f;
     int cur_n = -1;             // sample of the plane whose row phase is pending
+    if (HAS_STATS || HAS_BST)
+        ru3d_clear_own_slab_rows(a.stat_slab, (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave, a.N, 32 * 2);
     auto stat_flush = [&]() {
         if (!(HAS_STATS || HAS_BST) || cur_n < 0) return;
         float* dst = a.stat_slab + ((((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * a.N + cur_n) * 32) * 2;

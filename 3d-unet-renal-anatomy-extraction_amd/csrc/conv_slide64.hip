@@ -136,9 +136,10 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
     const bf16* bl = lds + ((lane & 15) + 16 * hfw) * PITCH + (lane >> 4) * 8;
 
     // fused InstanceNorm statistics: slab[workgroup][wave][n][CB][2]; a wave fills its own 16 channels, the rest of
-    // its row stays at the zeros the caller wrote
+    // its row stays at the zeros it wrote when the kernel started
     float st1[8], st2[8];
     int cur_n = -1;
+    if (SUMS) ru3d_clear_own_slab_rows(a.stat_slab, (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave, a.N, CB * 2);
     auto stat_flush = [&]() {
         if (!SUMS || cur_n < 0) return;
         float* dst = a.stat_slab + ((((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * a.N + cur_n) * CB) * 2;

@@ -302,12 +302,9 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s2_dma_kernel(WS2Args a) {
     }
 }
 
-// ---- dispatch.  mode 2 (default): the LDS-DMA kernel (16-wide tiles, two cout tiles per workgroup when Cout % 64 == 0);
-// mode 1: the register-staged kernel; 0: neither (wgrad_staged_mfma_kernel)
-static int s2_mode() {
-    static const int mode = getenv("RU3D_WGRAD_S2") ? atoi(getenv("RU3D_WGRAD_S2")) : 2;
-    return mode;
-}
+// ---- dispatch: the LDS-DMA kernel (16-wide tiles, two cout tiles per workgroup when Cout % 64 == 0) where W fits its
+// tiles, the register-staged kernel elsewhere
+static int s2_mode() { return 2; }
 static bool s2_dma(const WgradGeom& g) {
     return s2_mode() >= 2 && (g.Wo % DW) == 0 &&
            (int64_t)g.Di * g.Hi * g.Wi * g.ldx < (1ll << 30) && (int64_t)g.Do * g.Ho * g.Wo * g.lddy < (1ll << 30);

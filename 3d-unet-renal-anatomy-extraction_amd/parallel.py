@@ -24,7 +24,7 @@ Design (MI355X: 7 xGMI links per GPU, point-to-point):
   * `exchange="rs_ag"`: reduce-scatter + all-gather (`ru3d_comm_reduce_scatter` / `_all_gather`) instead of one
     all-reduce - the form SURVEY 8(e) asks for on point-to-point xGMI; same result;
   * `reserve_cus=n` (default 16 when world > 1, RU3D_RESERVE_CUS): the persistent conv kernels size their grids for the
-    device's CUs minus n (`ru3d_set_cu_budget`), so RCCL's reduction kernels on the side stream find free CUs;
+    device's CUs minus n (`ru3d_set_cu_budget_device`: a per-device value), so RCCL's reduction kernels on the side stream find free CUs;
   * every rank must end up on the same transport: `negotiate_transport` votes (MIN over ranks of "librccl loads
     here") before any rank enters the collective communicator set-up, and a failed set-up is voted on again;
   * parameters that never receive a gradient (the unused skip_conv of same-shape ResBlocks, reference
@@ -207,7 +207,10 @@ class GradSync:
             if reserve_cus > 0:
                 N = self.comm.N
                 total = torch.cuda.get_device_properties(dev).multi_processor_count
-                N.check(N.lib.ru3d_set_cu_budget(max(8, total - int(reserve_cus))), "set_cu_budget")
+                # the budget belongs to the model's DEVICE (ru3d_set_cu_budget_device): another model of this process on
+                # another device keeps its own
+                self._budget_dev = dev.index if dev.index is not None else torch.cuda.current_device()
+                N.check(N.lib.ru3d_set_cu_budget_device(self._budget_dev, max(8, total - int(reserve_cus))), "set_cu_budget")
                 self._reserved = int(reserve_cus)
         backend = dist.get_backend(process_group)
         self._avg_op = dist.ReduceOp.AVG if backend == "nccl" else None
@@ -358,7 +361,7 @@ class GradSync:
         except ImportError:
             pass
         if getattr(self, "_reserved", 0) and getattr(self, "comm", None) is not None:
-            self.comm.N.lib.ru3d_set_cu_budget(0)
+            self.comm.N.lib.ru3d_set_cu_budget_device(self._budget_dev, 0)
             self._reserved = 0
         if getattr(self, "_owns_comm", False) and self.comm is not None:
             self.comm.destroy()

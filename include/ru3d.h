@@ -456,14 +456,17 @@ int ru3d_comm_all_gather(void* comm, void* buf, int64_t count_per_rank, int dtyp
  * rank vote on the transport BEFORE any rank enters the collective ru3d_comm_init. */
 int ru3d_comm_available(void);
 int ru3d_comm_destroy(void* comm);
-/* Compute units the persistent conv kernels may occupy (their grids are sized from it); 0 restores the device's count.
- * A data-parallel rank leaves a few CUs to RCCL's reduction kernels on the side stream. */
 /* Kernel probe (bench.py's `roofline` object): between begin and end the library records a HIP-event pair on the launch
  * stream around the main kernel of every 3x3x3 stride-1 conv launch (forward or input gradient, any entry point) whose
  * output grid is n x d x h x w with cin -> cout channels; `end` waits for them and returns their number and the sum of
  * their durations.  Launches made while the stream is being captured into a graph are skipped. */
 int ru3d_probe_begin(int n, int d, int h, int w, int cin, int cout);
 int ru3d_probe_end(int* launches, double* total_ms);
+/* Compute units the persistent conv kernels launched on a device may occupy (their grids are sized from it); 0 restores
+ * the device's count.  A data-parallel rank leaves a few CUs to RCCL's reduction kernels on the side stream.  The value
+ * belongs to the DEVICE (the CUs being divided are that device's): every entry point uses the budget of the device its
+ * stream lives on.  ru3d_set_cu_budget / ru3d_get_cu_budget address the calling thread's current device. */
+int ru3d_set_cu_budget_device(int device, int cus);
 int ru3d_set_cu_budget(int cus);
 int ru3d_get_cu_budget(void);
 /* dst[i] = (dst_dtype)(src[i] * scale) on flat 16-byte-aligned device arrays, f32 <-> bf16: the copy-in / copy-out

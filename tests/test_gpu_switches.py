@@ -22,8 +22,10 @@ CHILD = os.path.join(ROOT, "tests", "switch_child.py")
 SWITCHES = {
     "in": [{"RU3D_CONV_S2": "0", "RU3D_FUSED_SKIP": "0", "RU3D_DGRAD_PAIR": "0"},       # round-2 direct forms, unfused tails
            {"RU3D_CONV_SLIDE64": "0", "RU3D_WGRAD_SLIDE": "0", "RU3D_CONV_PC": "0"},    # no sliding 64-channel / wgrad kernels
-           {"RU3D_CONV_KSPLIT": "2", "RU3D_CONV_WS": "2", "RU3D_STEM_MFMA": "0"},        # split-K x2, whole-sample conv, VALU stem
-           {"RU3D_SKIP_LINK": "0", "RU3D_WGRAD_S2": "1", "RU3D_WGRAD_BLOCKS": "256"}],   # concat copies, register-staged s2 wgrad
+           {"RU3D_CONV_WS": "2", "RU3D_STEM_MFMA": "0", "RU3D_HEAD_FUSED": "0"},         # whole-sample conv, VALU stem, unfused head backward
+           {"RU3D_SKIP_LINK": "0", "RU3D_WGRAD_DIRECT": "0", "RU3D_WGRAD_STREAM": "0"},  # concat copies, slabs at 8^3, one stream
+           # round 4: norm.hip's three launches on the small levels, the interleaved concat on the full-resolution level
+           {"RU3D_IN_SMALL": "0", "RU3D_PLANAR_CONCAT": "0"}],
     "c4": [{"RU3D_CONV_TILEFIT": "0", "RU3D_SLIDE64_EDGE": "0", "RU3D_CONV_WS": "0"},    # round-2 tilings of the odd extents
            {"RU3D_PAD_CHANNELS": "0"}],                                                   # F = 30 on the generic kernels
 }
