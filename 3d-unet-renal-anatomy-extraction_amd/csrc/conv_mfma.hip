@@ -819,9 +819,7 @@ bool mfma_conv_can_fuse_bwd_sums(const ConvGeom& g) {
     if (!(g.k == 3 && g.stride == 1 && !g.transposed)) return false;
     SlidePlan sp;
     if (g.Cin == 32) return slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp);
-    static const int mode64 = getenv("RU3D_DGRAD_IN_FUSE64") ? atoi(getenv("RU3D_DGRAD_IN_FUSE64")) : 1;
-    if (mode64 && g.Cin == 64 && (g.Cout == 64 || g.Cout == 128)) return slide64_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp);
-    return false;
+    return false;      // (the 64-channel kernel's variant was removed in round 4: time-neutral at best, see conv_slide64.hip)
 }
 
 int mfma_conv_bwd_sums_finalize(const ConvGeom& g, const float* slab, float* m12, hipStream_t st) {

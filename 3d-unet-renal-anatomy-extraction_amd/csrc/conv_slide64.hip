@@ -51,7 +51,6 @@ struct Slide64Args {
     int flip;
     int cout_total;                       // Cout of the conv (64 per grid.y slice)
     int tiles_h, tiles_w, dsplit, DL, units;
-    float slope, inv_slope;               // HAS_BST: LeakyReLU slope of the activation being differentiated
     int light_last;                       // EDGE: the last column's far W half lies outside the volume (W % 32 in 1..16)
 };
 
@@ -89,15 +88,13 @@ __device__ __forceinline__ void mfma16(f32x4& acc, const bf16x8& w, const bf16x8
 // partly outside the volume.  Its staged pieces already come back as zeros; the epilogue masks stores, residual reads and
 // statistics per voxel, and a W half that lies outside entirely issues no MFMAs (its passes still carry their share of
 // the staging and of the previous plane's epilogue).  A separate instantiation: the W % 32 == 0 code is unchanged.
-// HAS_BST (input-gradient role in front of an InstanceNorm + LeakyReLU backward, as in conv_slide32.hip): the conv output is
-// the gradient wrt the activation a = lrelu(xhat); `res` / `ldr` carry that activation and the row phase takes the two sums
-// the backward needs - sum g' and sum g' xhat with g' = g lrelu'(a), xhat recovered from a - into the statistics slab: the
-// separate reduction pass over (g, a) disappears on the 64-channel level too.  The stored output is g, unchanged.
-template <bool HAS_RES, bool HAS_STATS, int VG, bool EDGE = false, bool HAS_BST = false>
+// (Rounds 2-3 carried a HAS_BST variant - the InstanceNorm-backward sums of the following norm from this kernel's row phase, as
+// in conv_slide32.hip.  It spilled 57 registers outside its loop and measured time-neutral to slightly slower in two
+// same-box A/Bs (round 4: 16.39 vs 16.25 ms with it on); removed.)
+template <bool HAS_RES, bool HAS_STATS, int VG, bool EDGE = false>
 __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a) {
-    static_assert(!HAS_BST || (!HAS_RES && !HAS_STATS && VG == 1), "backward sums: their own variant of the 64-cout form");
-    constexpr bool SUMS = HAS_STATS || HAS_BST;        // st1 / st2 and the slab are in use
-    constexpr bool LOADS = HAS_RES || HAS_BST;         // a second tensor is read in the row phase
+    constexpr bool SUMS = HAS_STATS;                   // st1 / st2 and the slab are in use
+    constexpr bool LOADS = HAS_RES;                    // a second tensor is read in the row phase
     __shared__ __attribute__((aligned(16))) bf16 lds[RING * PLANE];
     __shared__ __attribute__((aligned(16))) bf16 est_s[4 * 128 * EP];   // epilogue patches (stored values), one per wave
     const int tid = threadIdx.x, lane = tid & 63;
@@ -300,16 +297,6 @@ __global__ __launch_bounds__(256, 1) void conv3_s1_slide64_kernel(Slide64Args a)
                     st2[i] = fmaf(v[i], v[i], st2[i]);
                 }
             }
-            if constexpr (HAS_BST) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const float act = (float)rres[i];
-                    const float gp = act > 0.f ? v[i] : v[i] * a.slope;
-                    const float xh = act > 0.f ? act : act * a.inv_slope;
-                    st1[i] += gp;
-                    st2[i] = fmaf(gp, xh, st2[i]);
-                }
-            }
             if constexpr (HAS_RES) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) v[i] += (float)rres[i];
@@ -484,8 +471,7 @@ int conv_slide64_launch(const void* x, const void* w, const float* bias, const v
         return ru3d_fail(-1, "conv_slide64: shape not supported");
     if ((int64_t)g.Do * g.Ho * g.Wo * g.ldx >= (1ll << 30)) return ru3d_fail(-1, "conv_slide64: sample too large");
     if (res && stat_slab) return ru3d_fail(-1, "conv_slide64: residual and fused statistics cannot be combined");
-    if (bst_act && (res || !stat_slab || g.Cout == 32 || bias))
-        return ru3d_fail(-1, "conv_slide64: backward sums go with a slab, without residual / bias, on the 64-cout form");
+    if (bst_act) return ru3d_fail(-1, "conv_slide64: no fused backward sums on the 64-channel kernel");
     Slide64Args a;
     a.x = (const bf16*)x;
     a.w = (const bf16x8*)w;
@@ -508,8 +494,7 @@ int conv_slide64_launch(const void* x, const void* w, const float* bias, const v
     a.flip = g.flip;
     a.cout_total = g.Cout;
     a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w; a.dsplit = p.dsplit; a.DL = p.DL; a.units = p.units;
-    a.slope = slope; a.inv_slope = slope != 0.f ? 1.f / slope : 0.f;
-    if (bst_act) { a.res = (const bf16*)bst_act; a.ldr = bst_ld; }
+    (void)bst_ld; (void)slope;
     a.light_last = (g.Wo % TW) != 0 && (g.Wo % TW) <= 16 && p.tiles_w > 1;
     const dim3 grid(p.grid, p.ny), block(256);
 #define RU3D_S64_LAUNCH(VGV, EDGEV)                                                                                      \
@@ -519,10 +504,7 @@ int conv_slide64_launch(const void* x, const void* w, const float* bias, const v
         else hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, false, VGV, EDGEV>), grid, block, 0, st, a);             \
     } while (0)
     const bool edge = (g.Wo % TW) != 0;
-    if (bst_act) {
-        if (edge) hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, false, 1, true, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((conv3_s1_slide64_kernel<false, false, 1, false, true>), grid, block, 0, st, a);
-    } else if (g.Cout == 32) {
+    if (g.Cout == 32) {
         if (edge) RU3D_S64_LAUNCH(2, true);
         else RU3D_S64_LAUNCH(2, false);
     } else {

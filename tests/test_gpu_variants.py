@@ -260,7 +260,14 @@ def test_attention_gate_16_bit_and_padded(feat, dtype):
     network.set_compute_dtype(model, dtype)
     assert model.net._pad == (feat == 30)
     logits = model(x)
-    assert (logits - ref).abs().max().item() <= (0.12 if dtype == torch.bfloat16 else 0.03)
+    # Yardstick: the relative L2 distance to the fp32 run - stable to three digits across kernel families and seeds
+    # (profiles/r04_attention_gate_yardstick.txt: 0.029-0.045 bf16, 0.0036-0.0057 fp16, the same values with the small
+    # levels' norm kernels old or new) - plus a loose bound on the largest single deviation, which is one voxel's rounding
+    # luck: 0.098-0.124 bf16 over three seeds and two kernel families, on either side of the 0.12 this test used to allow.
+    d = (logits - ref).float()
+    rel = (d.norm() / ref.float().norm()).item()
+    assert rel <= (0.06 if dtype == torch.bfloat16 else 0.008), rel
+    assert d.abs().max().item() <= (0.2 if dtype == torch.bfloat16 else 0.03)
     L.HybirdLoss()(logits, y).backward()
     for k, p in model.named_parameters():
         if p.grad is not None:

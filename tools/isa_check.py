@@ -25,11 +25,11 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "3d-unet-renal-anatomy-extraction_amd", "csrc")
 SRCS = ["conv_slide32.hip", "conv_slide64.hip", "conv_s2.hip", "conv_ws.hip", "fused_skip.hip", "wgrad_slide.hip", "wgrad_s2.hip", "conv_mfma.hip", "small_convs.hip", "conv_generic.hip",
-        "norm.hip", "loss.hip", "predict.hip", "comm.hip"]
+        "norm.hip", "norm_small.hip", "loss.hip", "predict.hip", "comm.hip"]
 TWICE = {"conv_slide32.hip", "conv_slide64.hip", "conv_s2.hip", "conv_ws.hip", "fused_skip.hip", "wgrad_slide.hip", "wgrad_s2.hip", "conv_mfma.hip", "small_convs.hip", "conv_generic.hip",
-         "norm.hip"}
+         "norm.hip", "norm_small.hip"}
 # spilled VGPRs tolerated per kernel-name pattern (everything else: 0)
-ALLOW = [(r"convt3_s2_tile_kernel", 8), (r"conv3_s1_slide32_kernel", 64), (r"conv3_s1_slide64_kernel", 64), (r"conv3_s1_pc_kernel", 32), (r"wgrad3_s1_slide_kernel", 16), (r"conv3_s1_ws_kernel", 8)]
+ALLOW = [(r"convt3_s2_tile_kernel", 8), (r"conv3_s1_slide32_kernel", 64), (r"conv3_s1_slide64_kernel", 64), (r"conv3_s1_pc_kernel", 40), (r"wgrad3_s1_mfma_kernel", 4), (r"wgrad3_s1_slide_kernel", 16), (r"conv3_s1_ws_kernel", 8)]
 NO_SCRATCH_IN_MFMA_SPAN = [r"wgrad3_s1_slide_kernel"]
 NO_COPY_INTO_MFMA_OPERANDS = [r"conv3_s1_slide32_kernel", r"conv3_s1_slide64_kernel"]
 
