@@ -90,7 +90,7 @@ SIGNATURES = {
     "ru3d_in_lrelu_fwd": (_i, [_P, _vp, _vp, _P, _P, _f, _i, _vp]),
     "ru3d_skip1x1_in_lrelu_fwd_supported": (_i, [_P, _P, _P, _i]),
     "ru3d_skip1x1_in_lrelu_fwd": (_i, [_P, _vp, _vp, _P, _vp, _vp, _P, _f, _i, _vp]),
-    "ru3d_in_lrelu_bwd": (_i, [_P, _P, _P, _vp, _vp, _P, _P, _vp, _sz, _f, _i, _vp, _i, _vp]),
+    "ru3d_in_lrelu_bwd": (_i, [_P, _P, _P, _vp, _vp, _P, _P, _vp, _sz, _f, _i, _vp, _vp, _i, _vp]),
     "ru3d_in_lrelu_bwd_apply": (_i, [_P, _P, _vp, _vp, _vp, _P, _f, _i, _i, _vp]),
     "ru3d_conv3d_dgrad_in_bwd_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),
     "ru3d_conv3d_dgrad_in_bwd": (_i, [_P, _vp, _P, _vp, _vp, _P, _P, _i, _i, _f, _i, _vp, _sz, _vp]),

@@ -548,7 +548,8 @@ def skip1x1_in_lrelu_fwd(x, pw, bias, y, mean, scale, out=None):
     return out
 
 
-def in_lrelu_bwd(gout, out, y, mean, scale, want_gpre=False, zero_far=False, want_gpre_sum=False):
+def in_lrelu_bwd(gout, out, y, mean, scale, want_gpre=False, zero_far=False, want_gpre_sum=False, dy_sum=None):
+    """dy_sum: optional float32 [C] tensor that receives the channel sums of dy (the producing conv's bias gradient)."""
     n, c, d, h, w = y.shape
     dy = N.new_act(n, c, d, h, w, y.dtype, y.device)
     gpre = N.new_act(n, c, d, h, w, y.dtype, y.device) if want_gpre else None
@@ -557,8 +558,8 @@ def in_lrelu_bwd(gout, out, y, mean, scale, want_gpre=False, zero_far=False, wan
     ws = N.workspace(N.lib.ru3d_reduce_workspace_bytes(ref(dyy)), y.device)
     gsum = torch.empty(c, dtype=torch.float32, device=y.device) if (want_gpre and want_gpre_sum) else None
     check(N.lib.ru3d_in_lrelu_bwd(ref(dg), ref(do), ref(dyy), ptr(mean), ptr(scale), ref(ddy), ref(dp), ptr(ws),
-                                  ws.numel(), LRELU_SLOPE, 1 if zero_far else 0, ptr(gsum), N.dtype_code(y.dtype),
-                                  stream()), "in_lrelu_bwd")
+                                  ws.numel(), LRELU_SLOPE, 1 if zero_far else 0, ptr(gsum), ptr(dy_sum),
+                                  N.dtype_code(y.dtype), stream()), "in_lrelu_bwd")
     if want_gpre_sum:
         return dy, gpre, gsum
     return dy, gpre
@@ -1223,12 +1224,13 @@ class UpFn(torch.autograd.Function):
             u = out[:, :cout_p] if ctx.has_skip else out
             gu = g[:, :cout_p] if ctx.has_skip else g
             gskip = g[:, cout_p:] if ctx.has_skip else None
-        dy, _ = in_lrelu_bwd(gu, u, y, mean, scale, zero_far=True)
+        gb = torch.empty(y.shape[1], dtype=torch.float32, device=y.device)
+        dy, _ = in_lrelu_bwd(gu, u, y, mean, scale, zero_far=True, dy_sum=gb)       # bias gradient: sums of dy
+        gb = gb[:cout]
         nvox = x.shape[0] * x.shape[2] * x.shape[3] * x.shape[4]
         with _OnSide(x.device, nvox, (x, dy)):
             # the ConvTranspose3d weight is [Cin][Cout][27]: its outer dimension is the module's in_channels
             gw = unpad_wgrad(convt_wgrad(x, dy, key=ctx.wkey), cin, cout, cin_seg, cout_seg)
-            gb = channel_sum(dy)[:cout]
         gx = None
         if ctx.needs_input_grad[0]:
             gx = convt_dgrad(dy, pwd, tuple(x.shape))

@@ -597,7 +597,7 @@ extern "C" int ru3d_conv3d_dgrad_in_bwd(const ru3d_tensor* dy, const void* w_pac
     // not a shape the sliding kernel takes: the two entry points one after the other (they share the workspace in stream order)
     int rc = ru3d_conv3d_dgrad(dy, w_packed, nullptr, da, k, stride, dtype, ws, ws_bytes, stream);
     if (rc) return rc;
-    return ru3d_in_lrelu_bwd(da, act, act, mean, scale, dyn, nullptr, ws, ws_bytes, slope, 0, nullptr, dtype, stream);
+    return ru3d_in_lrelu_bwd(da, act, act, mean, scale, dyn, nullptr, ws, ws_bytes, slope, 0, nullptr, nullptr, dtype, stream);
 }
 
 static WgradGeom make_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, int k, int stride) {

@@ -1,6 +1,16 @@
-// The stride-2 forms of the top two level boundaries (128^3 <-> 64^3, 64^3 <-> 32^3) as LDS-tiled, D-sliding, persistent
-// kernels on v_mfma_f32_16x16x32 (reference network.py:311-314 ConvTranspose3d k3 s2 p1 + far pad, :394 the pooling
-// ResBlock's stride-2 conv1, :403 its 1x1x1 stride-2 skip_conv, and the input gradients of the three):
+// The stride-2 forms of the TOP level boundary (128^3 <-> 64^3 of config 2: 32 <-> 64 channels) as LDS-tiled, D-sliding,
+// persistent kernels on v_mfma_f32_16x16x32 (reference network.py:311-314 ConvTranspose3d k3 s2 p1 + far pad, :394 the
+// pooling ResBlock's stride-2 conv1, :403 its 1x1x1 stride-2 skip_conv, and the input gradients of the three).
+//
+// SCOPE (t_plan / g_plan below): T form Cin = 64 with Cout 32 or 64, G form Cin = 32 with Cout 64 or 128 - config 2's
+// 32 <-> 64 channel boundary in both directions and nothing else.  The 64^3 <-> 32^3 boundary (64 <-> 128
+// channels) and everything deeper do NOT run here and are not meant to: the design keeps a consumer wave's weights in
+// registers for the whole launch (T form: up to 8 taps x Cin x 32 couts), which at Cin = 128 / Cout = 64 is 8 x 16 KB
+// per wave - four times the register file - and the LDS plane ring (5 planes x (TH+2) rows x W x Cin) no longer fits
+// two workgroups per CU at 64 channels in, 3 input rows out.  Those shapes stay on conv_gather_mfma_kernel /
+// convt_tile_mfma_kernel / conv_direct_mfma_kernel (conv_mfma.hip), 0.06-0.08 ms each, 0.23 ms of the step in
+// profiles/r04_kernel_trace_by_grid.txt; they are weight-bandwidth bound like the other deep-level kernels
+// (profiles/r04_pmc_deep_levels.txt), not HBM bound.
 //
 //   T form  in [n^3, Cin] -> out [(2n)^3, Cout]: ConvTranspose3d forward, input gradient of the stride-2 conv
 //           (+ optionally, in the same launch: the input gradient of the 1x1x1 stride-2 skip conv, whose only non-zero

@@ -319,13 +319,21 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(const T* __restrict__
                                                            T* __restrict__ gpre, int ldgp, float slope, int zero_far,
                                                            int D, int H, int W, ChanLoop cl, int C,
                                                            const float* __restrict__ shift = nullptr,
-                                                           const float* __restrict__ oscale = nullptr) {
+                                                           const float* __restrict__ oscale = nullptr,
+                                                           double* __restrict__ dysum_part = nullptr) {
     // AFFINE (BatchNorm): xhat = y * scale + shift, dy = oscale * (...) with per-(n, c) values; `mean` unused
+    // dysum_part: per-block sums of the stored dy (the bias gradient of the conv / transposed conv in front of the
+    // norm is the sum of dy over samples and voxels) in reduce2_kernel's partial layout: no separate pass over dy
+    __shared__ float dsh[256][VEC + 1];
     const int tid = threadIdx.x;
     const int cgl = tid % cl.Gb, vl = tid / cl.Gb;
     const int cg = blockIdx.z * cl.Gb + cgl;
     const int n = blockIdx.y;
-    if (vl >= cl.vpb || cg >= cl.G) return;
+    const bool active = vl < cl.vpb && cg < cl.G;
+    float dsum[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; i++) dsum[i] = 0.f;
+    if (active) {
     float mu[VEC], sc[VEC], m1[VEC], m2[VEC], osc[VEC];
 #pragma unroll
     for (int i = 0; i < VEC; i++) {
@@ -371,6 +379,25 @@ __global__ __launch_bounds__(256) void in_lrelu_bwd_kernel(const T* __restrict__
         }
         store_vec<T, VEC>(dy + row * lddy + cg * VEC, dv);
         if (HAS_GPRE && !FROM_GPRE) store_vec<T, VEC>(gpre + row * ldgp + cg * VEC, pv);
+        if (dysum_part) {
+#pragma unroll
+            for (int i = 0; i < VEC; i++) dsum[i] += to_f32<T>(from_f32<T>(dv[i]));      // the stored value
+        }
+    }
+    }
+    if (!dysum_part) return;
+#pragma unroll
+    for (int i = 0; i < VEC; i++) dsh[tid][i] = active ? dsum[i] : 0.f;
+    __syncthreads();
+    if (vl == 0 && cg < cl.G) {
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+            double t = 0.0;
+            for (int l = 0; l < cl.vpb; l++) t += (double)dsh[l * cl.Gb + cgl][i];      // fixed order
+            double* pp = dysum_part + (((int64_t)n * cl.chunks + blockIdx.x) * C + cg * VEC + i) * 2;
+            pp[0] = t;
+            pp[1] = 0.0;
+        }
     }
 }
 
@@ -460,7 +487,8 @@ static size_t reduce_ws_bytes(const ru3d_tensor* t) {
     int64_t V = (int64_t)t->d * t->h * t->w;
     int64_t chunks = V < 4096 ? V : 4096;
     if (chunks < 1) chunks = 1;
-    return (size_t)t->n * chunks * t->c * 2 * sizeof(double) + (size_t)t->n * t->c * 2 * sizeof(float) + 256;
+    // reduction partials + m12 + (in_lrelu_bwd with dy_sum) the apply pass's dy-sum partials
+    return 2 * (size_t)t->n * chunks * t->c * 2 * sizeof(double) + (size_t)t->n * t->c * 2 * sizeof(float) + 512;
 }
 
 #ifndef RU3D_STORAGE_F16
@@ -537,7 +565,7 @@ extern "C" int ru3d_in_lrelu_fwd(const ru3d_tensor* y, const float* mean, const 
 template <typename T>
 static int in_bwd_impl(const ru3d_tensor* gout, const ru3d_tensor* out, const ru3d_tensor* y, const float* mean,
                        const float* scale, const ru3d_tensor* dy, const ru3d_tensor* gpre, void* ws, float slope,
-                       int zero_far, float* gpre_sum, hipStream_t st) {
+                       int zero_far, float* gpre_sum, float* dy_sum, hipStream_t st) {
     const int64_t V = (int64_t)y->d * y->h * y->w;
     const int vec = pick_vec<T>(y->c, {gout, out, y, dy, gpre});
     ChanLoop cl = make_chanloop(V, y->c, vec, 64, y->n);
@@ -562,27 +590,34 @@ static int in_bwd_impl(const ru3d_tensor* gout, const ru3d_tensor* out, const ru
     if (rc) return rc;
     ChanLoop ca = make_chanloop(V, y->c, vec, 16, y->n);
     dim3 grida(ca.chunks, y->n, (ca.G + ca.Gb - 1) / ca.Gb);
+    // dy-sum partials of the apply pass: behind the reduction partials and m12 (both still in use while it runs)
+    double* dpart =
+        dy_sum ? (double*)((char*)m12 + (((size_t)y->n * y->c * 2 * sizeof(float) + 255) / 256) * 256) : nullptr;
 #define CALL(TT, VV)                                                                                                  \
     if (gpre)                                                                                                         \
         hipLaunchKernelGGL((in_lrelu_bwd_kernel<TT, VV, true, true>), grida, dim3(256), 0, st, (const TT*)gout->ptr,  \
                            gout->ld, (const TT*)out->ptr, out->ld, (const TT*)y->ptr, y->ld, mean, scale,            \
                            (const float*)m12, (TT*)dy->ptr, dy->ld, (TT*)gpre->ptr, gpre->ld, slope, zero_far, y->d,  \
-                           y->h, y->w, ca, y->c);                                                                     \
+                           y->h, y->w, ca, y->c, (const float*)nullptr, (const float*)nullptr, dpart);               \
     else                                                                                                              \
         hipLaunchKernelGGL((in_lrelu_bwd_kernel<TT, VV, false>), grida, dim3(256), 0, st, (const TT*)gout->ptr,       \
                            gout->ld, (const TT*)out->ptr, out->ld, (const TT*)y->ptr, y->ld, mean, scale,            \
                            (const float*)m12, (TT*)dy->ptr, dy->ld, (TT*)0, 0, slope, zero_far, y->d, y->h, y->w, ca, \
-                           y->c)
+                           y->c, (const float*)nullptr, (const float*)nullptr, dpart)
     DISPATCH_VEC(T, vec, CALL)
 #undef CALL
-    return ru3d_check_launch("in_lrelu_bwd_apply");
+    rc = ru3d_check_launch("in_lrelu_bwd_apply");
+    if (rc || !dy_sum) return rc;
+    hipLaunchKernelGGL(chansum_finalize_kernel, dim3((y->c + FIN_CX - 1) / FIN_CX), dim3(256), 0, st,
+                       (const double*)dpart, ca.chunks, y->c, y->n, dy_sum);
+    return ru3d_check_launch("in_lrelu_bwd_dysum_finalize");
 }
 
 extern "C" int ru3d_in_lrelu_bwd(const ru3d_tensor* gout, const ru3d_tensor* out, const ru3d_tensor* y,
                                  const float* mean, const float* scale, const ru3d_tensor* dy,
                                  const ru3d_tensor* gpre, void* ws, size_t ws_bytes, float slope, int zero_far,
-                                 float* gpre_sum, int dtype, void* stream) {
-    RU3D_FWD_F16(dtype, ru3d_in_lrelu_bwd_f16(gout, out, y, mean, scale, dy, gpre, ws, ws_bytes, slope, zero_far, gpre_sum, dtype, stream));
+                                 float* gpre_sum, float* dy_sum, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_in_lrelu_bwd_f16(gout, out, y, mean, scale, dy, gpre, ws, ws_bytes, slope, zero_far, gpre_sum, dy_sum, dtype, stream));
     Ru3dDeviceGuard dev_guard(stream);
     RU3D_REQUIRE(!gpre_sum || gpre, "in_lrelu_bwd: gpre_sum needs the residual form (gpre != NULL)");
     RU3D_REQUIRE(tensor_ok(gout) && tensor_ok(out) && tensor_ok(y) && tensor_ok(dy), "in_lrelu_bwd: bad tensor");
@@ -593,12 +628,15 @@ extern "C" int ru3d_in_lrelu_bwd(const ru3d_tensor* gout, const ru3d_tensor* out
                  reduce_ws_bytes(y));
     RU3D_REQUIRE((int64_t)y->d * y->h * y->w < (1ll << 31), "in_lrelu_bwd: sample too large");
     // the small levels: one launch instead of three (norm_small.hip)
-    if (dtype == RU3D_BF16 && in_small_mode(out, gpre_sum != nullptr, gout, y, dy, gpre))
-        return in_small_bwd_launch(gout, nullptr, 0, out, y, mean, scale, dy, gpre, ws, slope, zero_far, gpre_sum, as_stream(stream));
+    if (dtype == RU3D_BF16 && in_small_mode(out, gpre_sum != nullptr, gout, y, dy, gpre)) {
+        int rc = in_small_bwd_launch(gout, nullptr, 0, out, y, mean, scale, dy, gpre, ws, slope, zero_far, gpre_sum, as_stream(stream));
+        if (rc || !dy_sum) return rc;
+        return ru3d_channel_sum(dy, dy_sum, ws, ws_bytes, dtype, stream);      // small tensors: a pass of its own
+    }
     if (dtype == RU3D_F32)
-        return in_bwd_impl<float>(gout, out, y, mean, scale, dy, gpre, ws, slope, zero_far, gpre_sum, as_stream(stream));
+        return in_bwd_impl<float>(gout, out, y, mean, scale, dy, gpre, ws, slope, zero_far, gpre_sum, dy_sum, as_stream(stream));
     if (dtype == RU3D_BF16)
-        return in_bwd_impl<bf16>(gout, out, y, mean, scale, dy, gpre, ws, slope, zero_far, gpre_sum, as_stream(stream));
+        return in_bwd_impl<bf16>(gout, out, y, mean, scale, dy, gpre, ws, slope, zero_far, gpre_sum, dy_sum, as_stream(stream));
     return ru3d_fail(-1, "in_lrelu_bwd: bad dtype %d", dtype);
 }
 

@@ -233,10 +233,13 @@ int ru3d_in_lrelu_fwd(const ru3d_tensor* y, const float* mean, const float* scal
  * read at all (one tensor pass less in each of the two kernels).  zero_far=1 additionally zeroes the last plane
  * of each spatial axis of dy (the constant-pad planes of ConvTrans3D).
  * gpre_sum (optional, C floats): sum over n and voxels of gpre - the bias gradient of a conv that feeds the
- * residual input (skip_conv, network.py:407-409); it falls out of the reduction this call runs anyway. */
+ * residual input (skip_conv, network.py:407-409); it falls out of the reduction this call runs anyway.
+ * dy_sum (optional, C floats): sum over n and voxels of the stored dy - the bias gradient of the conv or transposed
+ * conv that produced y (network.py:290-300); per-block sums in the epilogue of the pass that writes dy. */
 int ru3d_in_lrelu_bwd(const ru3d_tensor* gout, const ru3d_tensor* out, const ru3d_tensor* y, const float* mean,
                       const float* scale, const ru3d_tensor* dy, const ru3d_tensor* gpre, void* ws,
-                      size_t ws_bytes, float slope, int zero_far, float* gpre_sum, int dtype, void* stream);
+                      size_t ws_bytes, float slope, int zero_far, float* gpre_sum, float* dy_sum, int dtype,
+                      void* stream);
 /* out[c] = sum over n,d,h,w of t (bias gradients). */
 int ru3d_channel_sum(const ru3d_tensor* t, float* out, void* ws, size_t ws_bytes, int dtype, void* stream);
 /* nn.Dropout3d(p) channel mask (network.py:397-398,412-413): scale[n*C+c] = keep ? 1/(1-p) : 0,

@@ -155,3 +155,30 @@ def test_conv_dgrad_in_bwd_small(dt, n, c, dims):
     da = ops.conv_dgrad(dy2, pwd, tuple(act.shape), 3, 1)          # the stored form of the same gradient
     ref, _ = _bwd64(da, act, None, mean, scale, False, False)
     _close(got, ref, EPS[dt], 2e-5 * float(s64.max()), "dgrad + IN backward")
+
+
+@pytest.mark.parametrize("dt", DTYPES + [torch.float32], ids=["bf16", "fp16", "f32"])
+@pytest.mark.parametrize("n,c,dims", [(2, 32, (40, 36, 28)), (1, 64, (33, 20, 17)), (2, 128, (16, 16, 16)), (3, 24, (9, 10, 11)),
+                                      (2, 512, (8, 8, 8))])
+def test_in_lrelu_bwd_dy_sum(dt, n, c, dims):
+    """The transposed conv's bias gradient (network.py:290-300: sum of dy over samples and voxels) out of the pass that
+    writes dy, far planes zeroed as ConvTrans3D's padding wants: equal to the float64 sum of the STORED dy to the
+    rounding of float partial sums, on the three-launch path (large tensors) and the whole-instance path (small ones)."""
+    g = torch.Generator().manual_seed(n + c + sum(dims))
+    d, h, w = dims
+    yv = torch.randn(n, c, d, h, w, generator=g) * 1.5 + 0.2
+    gv = torch.randn(n, c, d, h, w, generator=g)
+    y = ops.as_input(yv.to(DEV), dt)
+    m64, s64 = _stats64(y, None)
+    mean = m64.float().reshape(-1).to(DEV)
+    scale = s64.float().reshape(-1).to(DEV)
+    out = ops.in_lrelu_fwd(y, mean, scale)
+    gout = ops.as_input(gv.to(DEV), dt)
+    dysum = torch.full((y.shape[1],), float("nan"), dtype=torch.float32, device=DEV)
+    dy, _ = ops.in_lrelu_bwd(gout, out, out, mean, scale, zero_far=True, dy_sum=dysum)
+    plain, _ = ops.in_lrelu_bwd(gout, out, out, mean, scale, zero_far=True)
+    assert torch.equal(dy, plain), "dy itself does not depend on the extra output"
+    ref = dy.double().sum(dim=(0, 2, 3, 4)).cpu()
+    mag = dy.double().abs().sum(dim=(0, 2, 3, 4)).cpu()
+    err = (dysum.double().cpu() - ref).abs()
+    assert bool((err <= 2e-6 * mag + 1e-6).all()), float((err / (mag + 1e-30)).max())
