@@ -531,6 +531,266 @@ __global__ __launch_bounds__(512, 2) void conv3_s1_pc_kernel(MfmaConvArgs a) {
     stat_flush();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// pc4: the producer/consumer kernel with 4 voxel tiles x 2 cout tiles of accumulators per consumer wave.
+// Why (profiles/r04_pc_ablation.txt): with 2 x 2 tiles per wave every v_mfma_32x32x16 needs 512 B of weights through
+// the CU's vector L1 (64 B/clk) and 512 B of activations out of LDS; four consumer waves at the MFMA rate ask the L1
+// for exactly its peak, so the weight loads, the producers' halo loads and the MFMAs end up in series: 71 us where
+// the MFMAs alone need 23-27 us (weight reloads removed: -15 us, producers' global loads removed: -12 us).  Here
+//   * a consumer wave owns a 128-voxel x 64-cout block: 8 accumulators (128 AGPRs), a weight fragment serves four
+//     MFMAs: half the L1 bytes per MFMA, the same LDS bytes;
+//   * channel chunks of 16 (one MFMA k-step, 27 steps per item) so that two 512-voxel halo buffers fit: 32-byte voxel
+//     slots, rows padded from 34 to 40 slots so that the slot's 16-byte halves can be XOR-swapped by bit 2 of the W
+//     position alone (a ds_read_b128 of 32 consecutive voxels then touches every bank equally, for every tap offset)
+//     and every fragment address is one of three per-lane bases + an immediate;
+//   * the halo is moved by LDS-DMA (no staging registers, out-of-volume pieces come back as zeros through the buffer
+//     range check), issued by the producer waves one item ahead; producers are the only waves that wait for it;
+//   * the weight ring runs across item boundaries (27 = 9 x 3 steps, ring depth 3), so a new item starts with its
+//     first fragments already in registers;
+//   * barriers wait for LDS traffic only (lgkmcnt): a consumer's weight loads stay in flight across them;
+//   * InstanceNorm statistics are kept in LDS between tiles (wave-private rows), not in registers.
+// Tile: 4 x 4 x 32 voxels (wave = D plane, accumulator m = H row, lane = W position).
+template <int WD>
+__global__ __launch_bounds__(512, 2) void conv3_s1_pc4_kernel(MfmaConvArgs a) {
+    constexpr int TD = 4, TH = 4, TW = 32, MT = 4, NT = 2;
+    constexpr int HH = TH + 2, HD = TD + 2, WW = TW + 2, WWP = 40;
+    constexpr int SLOTS = HD * HH * WWP;              // 32-byte voxel slots of one halo buffer (pads included)
+    constexpr int BUF = SLOTS * 16;                   // bf16 elements
+    constexpr int NCH = (SLOTS * 2) / 64;             // 1 KB DMA chunks per buffer
+    constexpr int NDMA = (NCH + 3) / 4;               // per producer wave
+    constexpr int S = 27, XD = 2;
+    constexpr int OOBV = (int)0x80000000;
+    static_assert((SLOTS * 2) % 64 == 0 && S % WD == 0, "whole DMA chunks; the ring must close over an item");
+    __shared__ __attribute__((aligned(1024))) bf16 lds[2 * BUF + 4 * MT * 32 * MF_PITCH];
+    __shared__ float statl[4][NT * 32 * 2];
+    __shared__ __attribute__((aligned(16))) float biasl[NT * 32];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= 4;
+    const int NTT = a.Cout / 32, KS = a.Cin / 16;
+    const int nchunks = KS;
+
+    const int G = gridDim.x, b = blockIdx.x;
+    const int L = G < 8 ? G : 8;
+    const int xcd = b % L, idx = b / L;
+    const int gx = (G - xcd + L - 1) / L;
+    const int t_begin = (int)(((int64_t)a.nblk * xcd) / L), t_end = (int)(((int64_t)a.nblk * (xcd + 1)) / L);
+    const int my_tiles = (t_begin + idx < t_end) ? (t_end - t_begin - idx + gx - 1) / gx : 0;
+    const int nitems = my_tiles * nchunks;
+
+    auto tile_origin = [&](int tile, int& n, int& d0, int& h0, int& w0) {
+        const int tw_i = tile % a.tiles_w;
+        tile /= a.tiles_w;
+        const int th_i = tile % a.tiles_h;
+        tile /= a.tiles_h;
+        const int td_i = tile % a.tiles_d;
+        n = tile / a.tiles_d;
+        d0 = td_i * TD;
+        h0 = th_i * TH;
+        w0 = tw_i * TW;
+    };
+
+    if (producer) {
+        // ------------------------------------------------------------------ producer waves: LDS-DMA of the next item
+        const int pw = wave - 4;
+        int rel[NDMA], zz[NDMA];
+#pragma unroll
+        for (int i = 0; i < NDMA; i++) {
+            const int piece = (i * 4 + pw) * 64 + lane;            // 16-byte piece of the buffer this lane fills
+            const int slot = piece >> 1;
+            const int zw = slot % WWP, zh = (slot / WWP) % HH, zd = slot / (WWP * HH);
+            const bool valid = (i * 4 + pw) < NCH && zw < WW;
+            const int part = (piece & 1) ^ ((zw >> 2) & 1);        // which half of the voxel's 32 bytes lives here
+            rel[i] = valid ? (((zd * a.H + zh) * a.W + zw) * a.ldx + part * 8) * 2 : OOBV;
+            zz[i] = valid ? (zd | (zh << 8) | (zw << 16)) : -1;
+        }
+        const int64_t sample_elems = (int64_t)a.D * a.H * a.W * a.ldx;
+        for (int it = 0; it <= nitems; it++) {
+            if (it < nitems) {
+                const int tile = t_begin + idx + (it / nchunks) * gx, ch = it % nchunks;
+                int n, d0, h0, w0;
+                tile_origin(tile, n, d0, h0, w0);
+                const ru3d_i32x4 rsrc = ru3d_buffer_rsrc(a.x + n * sample_elems, (int)(sample_elems * 2));
+                const int base = ((((d0 - 1) * a.H + (h0 - 1)) * a.W + (w0 - 1)) * a.ldx + ch * 16) * 2;
+                const bool interior = d0 >= 1 && d0 + TD + 1 <= a.D && h0 >= 1 && h0 + TH + 1 <= a.H && w0 >= 1 &&
+                                      w0 + TW + 1 <= a.W;
+                const bf16* dst = lds + (it & 1) * BUF;
+#pragma unroll
+                for (int i = 0; i < NDMA; i++) {
+                    if ((i * 4 + pw) < NCH) {
+                        int off = zz[i] >= 0 ? base + rel[i] : OOBV;
+                        if (!interior && zz[i] >= 0) {
+                            const int gd = d0 - 1 + (zz[i] & 255), gh = h0 - 1 + ((zz[i] >> 8) & 255),
+                                      gw = w0 - 1 + ((zz[i] >> 16) & 255);
+                            if (!(gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)) off = OOBV;
+                        }
+                        ru3d_lds_dma16(rsrc, dst + (i * 4 + pw) * 512, off);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer waves
+    const int co_blk = blockIdx.y * (NT * 32);
+    const int ph = lane >> 5, wl = lane & 31;
+    int xb[3];      // element offset of this lane's fragment piece for the three W offsets of a tap (wave's D plane)
+#pragma unroll
+    for (int tw = 0; tw < 3; tw++) {
+        const int zw = wl + tw;
+        xb[tw] = ((wave * HH) * WWP + zw) * 16 + ((ph ^ ((zw >> 2) & 1)) << 3);
+    }
+    const bf16x8* wbase = a.w + (int64_t)blockIdx.y * NT * 64 + lane;
+    if (wave == 0) biasl[lane] = a.bias ? a.bias[co_blk + lane] : 0.f;
+    statl[wave][lane] = 0.f;
+    statl[wave][64 + lane] = 0.f;
+    int cur_n = -1;
+    if (a.stat_slab)
+        ru3d_clear_own_slab_rows(a.stat_slab, (int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave, a.N, NT * 32 * 2);
+    auto stat_flush = [&]() {       // this wave's LDS sums -> its slab row of sample cur_n
+        if (!a.stat_slab || cur_n < 0) return;
+        const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+        float* dst = a.stat_slab + ((((int64_t)blk * 4 + wave) * a.N + cur_n) * (NT * 32)) * 2;
+        dst[lane] = statl[wave][lane];
+        dst[64 + lane] = statl[wave][64 + lane];
+        statl[wave][lane] = 0.f;
+        statl[wave][64 + lane] = 0.f;
+    };
+
+    f32x16 acc[MT][NT];
+    bf16x8 wq[WD][NT];
+#pragma unroll
+    for (int s = 0; s < WD; s++) {      // the ring's first fragments: (tap s, chunk 0)
+        const int wtap = a.flip ? 26 - s : s;
+#pragma unroll
+        for (int t = 0; t < NT; t++) wq[s][t] = wbase[((int64_t)(wtap * KS) * NTT + t) * 64];
+    }
+
+    for (int it = 0; it <= nitems; it++) {
+        if (it >= 1) {
+            const int item = it - 1;
+            const int tile = t_begin + idx + (item / nchunks) * gx, ch = item % nchunks;
+            const int chn = ch + 1 == nchunks ? 0 : ch + 1;
+            const bf16* buf = lds + (item & 1) * BUF;
+            if (ch == 0) {
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+#pragma unroll
+                    for (int t = 0; t < NT; t++)
+#pragma unroll
+                        for (int i = 0; i < 16; i++) acc[m][t][i] = 0.f;
+            }
+            bf16x8 xq[XD][MT];
+#pragma unroll
+            for (int s = 0; s < XD; s++)
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+                    xq[s][m] = *reinterpret_cast<const bf16x8*>(&buf[xb[s % 3] + (((s / 9) * HH + m + (s / 3) % 3) * WWP) * 16]);
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int m = 0; m < MT; m++)
+                        acc[m][t] = RU3D_MFMA_32X32X16(wq[s % WD][t], xq[s % XD][m], acc[m][t], 0, 0, 0);
+                if (s + XD < S) {
+                    const int s1 = s + XD;
+#pragma unroll
+                    for (int m = 0; m < MT; m++)
+                        xq[s % XD][m] =
+                            *reinterpret_cast<const bf16x8*>(&buf[xb[s1 % 3] + (((s1 / 9) * HH + m + (s1 / 3) % 3) * WWP) * 16]);
+                }
+                {   // the ring never stops: the last WD steps fetch the first fragments of the next item's chunk
+                    const int s2 = s + WD < S ? s + WD : s + WD - S;
+                    const int c2 = s + WD < S ? ch : chn;
+                    const int wtap2 = a.flip ? 26 - s2 : s2;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) wq[s % WD][t] = wbase[((int64_t)(wtap2 * KS + c2) * NTT + t) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ch == nchunks - 1) {
+                // ---- epilogue through a wave-private LDS patch (see conv3_s1_pc_kernel): bias before the transpose,
+                // statistics and residual after it, 16-byte stores that cover whole 64-byte channel rows
+                int n, d0, h0, w0;
+                tile_origin(tile, n, d0, h0, w0);
+                if (a.stat_slab && n != cur_n) {
+                    stat_flush();
+                    cur_n = n;
+                }
+                bf16* est = lds + 2 * BUF + wave * (MT * 32 * MF_PITCH);
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    f32x4 bq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) bq[q] = *reinterpret_cast<const f32x4*>(&biasl[t * 32 + 8 * q + 4 * ph]);
+#pragma unroll
+                    for (int m = 0; m < MT; m++) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            float v[4];
+#pragma unroll
+                            for (int i = 0; i < 4; i++) v[i] = acc[m][t][q * 4 + i] + bq[q][i];
+                            store_vec<bf16, 4>(est + (m * 32 + wl) * MF_PITCH + 8 * q + 4 * ph, v);
+                        }
+                    }
+                    float st1[8], st2[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) st1[i] = st2[i] = 0.f;
+                    const int part = lane & 3;
+#pragma unroll
+                    for (int r = 0; r < 2 * MT; r++) {
+                        const int row = (lane >> 2) + 16 * r;
+                        const int od = d0 + wave, oh = h0 + (row >> 5), ow = w0 + (row & 31);
+                        float v[8];
+                        load_vec<bf16, 8>(est + row * MF_PITCH + part * 8, v);
+                        if (od < a.D && oh < a.H && ow < a.W) {
+                            const int64_t vox = (((int64_t)n * a.D + od) * a.H + oh) * a.W + ow;
+                            const int c0 = co_blk + t * 32 + part * 8;
+                            if (a.stat_slab) {
+#pragma unroll
+                                for (int i = 0; i < 8; i++) {
+                                    st1[i] += v[i];
+                                    st2[i] = fmaf(v[i], v[i], st2[i]);
+                                }
+                            }
+                            if (a.res) {
+                                float rr[8];
+                                load_vec<bf16, 8>(a.res + vox * a.ldr + c0, rr);
+#pragma unroll
+                                for (int i = 0; i < 8; i++) v[i] += rr[i];
+                            }
+                            store_vec<bf16, 8>(a.y + vox * a.ldy + c0, v);
+                        }
+                    }
+                    if (a.stat_slab) {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            float s1 = st1[i], s2 = st2[i];
+#pragma unroll
+                            for (int o = 4; o < 64; o <<= 1) {   // lanes that share (lane & 3) hold the same 8 channels
+                                s1 += __shfl_xor(s1, o, 64);
+                                s2 += __shfl_xor(s2, o, 64);
+                            }
+                            if (lane < 4) {
+                                const int c = t * 32 + lane * 8 + i;
+                                statl[wave][c * 2] += s1;
+                                statl[wave][c * 2 + 1] += s2;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    stat_flush();
+}
+
+
 static void pc_grid(int cout, bool nt2, int64_t nblk, int* gx, int* gy) {
     *gy = cout / (nt2 ? 64 : 32);
     int g = 256 / *gy;                 // one persistent workgroup per CU in total
@@ -556,6 +816,20 @@ static int launch_s1_pc(const MfmaConvArgs& a0, bool nt2, hipStream_t st) {
     else
         hipLaunchKernelGGL((conv3_s1_pc_kernel<TD, TH, TW, MT, 1, SWZ>), grid, dim3(512), 0, st, a);
     return ru3d_check_launch("conv3_s1_pc");
+}
+
+static int launch_s1_pc4(const MfmaConvArgs& a0, hipStream_t st) {
+    MfmaConvArgs a = a0;
+    a.tiles_d = (a.D + 3) / 4;
+    a.tiles_h = (a.H + 3) / 4;
+    a.tiles_w = (a.W + 31) / 32;
+    const int64_t nblk = (int64_t)a.N * a.tiles_d * a.tiles_h * a.tiles_w;
+    if (nblk > 0x7fffffff) return ru3d_fail(-1, "conv_mfma: grid too large");
+    a.nblk = (int)nblk;
+    int gx, gy;
+    pc_grid(a.Cout, true, nblk, &gx, &gy);
+    hipLaunchKernelGGL((conv3_s1_pc4_kernel<3>), dim3(gx, gy), dim3(512), 0, st, a);
+    return ru3d_check_launch("conv3_s1_pc4");
 }
 
 // y = bf16(sum_z part[z] + bias) (+ residual): fixed summation order, 8 channels (16 B) per thread
@@ -624,10 +898,11 @@ static int launch_s1(const MfmaConvArgs& a0, bool nt2, hipStream_t st) {
 struct S1Plan {
     int wclass;
     bool nt2, small, pc;
+    bool pc4;          // 512-voxel tiles, 4 x 2 accumulators per wave (conv3_s1_pc4_kernel)
     int64_t nblk_pc;   // spatial tiles of the producer/consumer decomposition
 };
 
-static S1Plan s1_plan(int N, int D, int H, int W, int Cout) {
+static S1Plan s1_plan(int N, int D, int H, int W, int Cout, int ldx) {
     auto cdiv = [](int x, int y) { return (x + y - 1) / y; };
     S1Plan p;
     const bool can_nt2 = (Cout % 64) == 0;
@@ -654,6 +929,18 @@ static S1Plan s1_plan(int N, int D, int H, int W, int Cout) {
     p.nt2 = can_nt2 && (!p.small || big * 2 >= 1024);
     static const int pc_mode = getenv("RU3D_CONV_PC") ? atoi(getenv("RU3D_CONV_PC")) : 1;   // 0 = off
     p.pc = !p.small && pc_mode >= 1 && (p.wclass >= 16 || fit_mode);
+    // the 512-voxel form: no more padded volume than the 2 x 4 x 32 tile, at least 3/4 of the CUs busy, a sample that
+    // a buffer descriptor can address (RU3D_CONV_PC4=0: off)
+    static const int pc4_mode = getenv("RU3D_CONV_PC4") ? atoi(getenv("RU3D_CONV_PC4")) : 1;
+    p.pc4 = false;
+    if (p.pc && p.nt2 && p.wclass == 32 && pc4_mode && (D % 4) == 0 && (H % 4) == 0 && ldx > 0 && (ldx % 8) == 0) {
+        const int64_t n4 = (int64_t)N * (D / 4) * (H / 4) * cdiv(W, 32);
+        const int64_t sample_bytes = (int64_t)D * H * W * ldx * 2;
+        if (n4 * (Cout / 64) >= 192 && sample_bytes < (1ll << 31)) {
+            p.pc4 = true;
+            p.nblk_pc = n4;
+        }
+    }
     return p;
 }
 
@@ -679,7 +966,7 @@ size_t conv_mfma_ws_bytes(const ConvGeom& g) {
     if (slide64_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) return 0;
     if (const int wsl = conv_ws_slices(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout))
         return (size_t)wsl * g.N * g.Do * g.Ho * g.Wo * g.Cout * sizeof(float);
-    const S1Plan p = s1_plan(g.N, g.Do, g.Ho, g.Wo, g.Cout);
+    const S1Plan p = s1_plan(g.N, g.Do, g.Ho, g.Wo, g.Cout, g.ldx);
     const int ks = s1_ksplit(p, g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout);
     return ks > 1 ? (size_t)ks * g.N * g.Do * g.Ho * g.Wo * g.Cout * sizeof(float) : 0;
 }
@@ -703,9 +990,10 @@ static int launch_s1_auto(const MfmaConvArgs& a, hipStream_t st) {
             return ru3d_check_launch("conv_ksplit_reduce");
         }
     }
-    const S1Plan p = s1_plan(a.N, a.D, a.H, a.W, a.Cout);
+    const S1Plan p = s1_plan(a.N, a.D, a.H, a.W, a.Cout, a.ldx);
     if (a.stat_slab && !p.pc) return ru3d_fail(-1, "conv_mfma: fused statistics need the producer/consumer kernel");
     if (!p.small) {
+        if (p.pc4) return launch_s1_pc4(a, st);
         if (p.pc && p.wclass == 32) return launch_s1_pc<2, 4, 32, 2, false>(a, p.nt2, st);
         if (p.pc && p.wclass == 16) return launch_s1_pc<2, 8, 16, 2, false>(a, p.nt2, st);
         if (p.pc && p.wclass == 8) return launch_s1_pc<4, 8, 8, 2, false>(a, p.nt2, st);
@@ -745,7 +1033,7 @@ bool mfma_conv_can_fuse_stats(const ConvGeom& g) {
     SlidePlan sp;
     if (slide_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) return true;
     if (slide64_conv_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, &sp)) return true;
-    return s1_plan(g.N, g.Do, g.Ho, g.Wo, g.Cout).pc;
+    return s1_plan(g.N, g.Do, g.Ho, g.Wo, g.Cout, g.ldx).pc;
 }
 
 static void stats_slab_geom(const ConvGeom& g, int* gx, int* gy, int* cb) {
@@ -762,7 +1050,7 @@ static void stats_slab_geom(const ConvGeom& g, int* gx, int* gy, int* cb) {
         *cb = g.Cout == 32 ? 32 : 64;
         return;
     }
-    const S1Plan p = s1_plan(g.N, g.Do, g.Ho, g.Wo, g.Cout);
+    const S1Plan p = s1_plan(g.N, g.Do, g.Ho, g.Wo, g.Cout, g.ldx);
     pc_grid(g.Cout, p.nt2, p.nblk_pc, gx, gy);
     *cb = p.nt2 ? 64 : 32;
 }
