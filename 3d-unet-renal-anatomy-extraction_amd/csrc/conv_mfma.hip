@@ -791,6 +791,243 @@ __global__ __launch_bounds__(512, 2) void conv3_s1_pc4_kernel(MfmaConvArgs a) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------
+// sk: the deep levels (16^3 x 256, 8^3 x 512 channels) with the accumulator blocking of pc4 and the reduction dimension
+// split over the workgroup's four consumer waves.  The 256-voxel x 32-cout tiles of conv3_s1_mfma_kernel give a wave 1 x 2
+// accumulators: 1 KB of activations from LDS and 512 B of weights through the L1 per MFMA, both pipes at their peak
+// (profiles/r04_pmc_deep_levels.txt).  4 x 2 accumulators halve both, but a 128-voxel x 64-cout block per WAVE leaves only
+// 64 blocks at 16^3 x 256: so all four waves of a workgroup work on the SAME 128 x 64 block, each on its own quarter of
+// the input channels (private halo buffers, 16-channel chunks moved by the producer waves' LDS-DMA one chunk ahead,
+// weight ring across chunks as in pc4); at the end the waves exchange accumulators through LDS - wave w keeps voxel tile
+// w and receives the three other waves' partial sums for it, added in a fixed order - and each runs the epilogue of its
+// 32 voxels.  gridDim.z > 1 splits the channels over workgroups as well (8^3: 4 x 4 = 16 slices of 32 channels): fp32
+// partial slices in a.part, summed by the caller's next kernel or conv_ksplit_reduce_kernel.
+// A wave numbers its accumulators from its own tile on (local m <-> voxel tile (m + wave) & 3): every register index is
+// static.  Tile: 2 x (64 / TW) x TW voxels; a fragment's 32 voxels are 32 / TW rows of TW.
+template <int TW>
+__global__ __launch_bounds__(512, 2) void conv3_s1_sk_kernel(MfmaConvArgs a) {
+    constexpr int TD = 2, TH = 64 / TW, R = 32 / TW, MT = 4, NT = 2, WD = 3;
+    constexpr int HD = TD + 2, HH = TH + 2, WW = TW + 2;
+    constexpr int SLOTS = HD * HH * WW;                  // real 32-byte voxel slots of one wave's halo
+    constexpr int NCH = (SLOTS * 2 + 63) / 64;           // 1 KB DMA chunks per halo
+    constexpr int BUF = NCH * 512;                       // bf16 elements per halo buffer (whole chunks)
+    constexpr int S = 27, XD = 2;
+    constexpr int OOBV = (int)0x80000000;
+    constexpr int REDF = 4 * 3 * NT * 4 * 64 * 4;        // floats of the accumulator exchange
+    static_assert(2 * 4 * BUF * 2 >= REDF * 4, "the exchange lives in the halo buffers");
+    __shared__ __attribute__((aligned(1024))) bf16 lds[2 * 4 * BUF];
+    __shared__ __attribute__((aligned(16))) bf16 patch[4][32 * MF_PITCH];
+    __shared__ __attribute__((aligned(16))) float biasl[NT * 32];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= 4;
+    const int cw = wave & 3;                              // consumer index (a producer feeds consumer cw)
+    const int NTT = a.Cout / 32, KS = a.Cin / 16;
+    const int cgs = a.Cout / 64;
+    const int bz = blockIdx.z, gz = gridDim.z;
+    const int cin_wave = a.Cin / (4 * gz);                // input channels of one wave
+    const int nch = cin_wave / 16;
+    const int k0 = (bz * 4 + cw) * nch;                   // first 16-channel chunk of this wave
+
+    // units in [cout group][tile] order, a contiguous run per XCD: the workgroups of an XCD share their weights
+    const int unit = xcd_remap(blockIdx.x, a.nblk * cgs);
+    const int cg = unit / a.nblk;
+    int tile = unit % a.nblk;
+    const int tw_i = tile % a.tiles_w;
+    tile /= a.tiles_w;
+    const int th_i = tile % a.tiles_h;
+    tile /= a.tiles_h;
+    const int td_i = tile % a.tiles_d;
+    const int n = tile / a.tiles_d;
+    const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+
+    if (producer) {
+        int rel[NCH], zz[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int piece = i * 64 + lane;
+            const int slot = piece >> 1;
+            const int zw = slot % WW, zh = (slot / WW) % HH, zd = slot / (WW * HH);
+            const bool valid = slot < SLOTS;
+            const int part = (piece & 1) ^ ((zw >> 2) & 1);
+            rel[i] = valid ? (((zd * a.H + zh) * a.W + zw) * a.ldx + part * 8) * 2 : OOBV;
+            zz[i] = valid ? (zd | (zh << 8) | (zw << 16)) : -1;
+        }
+        const int64_t sample_elems = (int64_t)a.D * a.H * a.W * a.ldx;
+        const ru3d_i32x4 rsrc = ru3d_buffer_rsrc(a.x + n * sample_elems, (int)(sample_elems * 2));
+        const bool interior = d0 >= 1 && d0 + TD + 1 <= a.D && h0 >= 1 && h0 + TH + 1 <= a.H && w0 >= 1 && w0 + TW + 1 <= a.W;
+        for (int it = 0; it <= nch; it++) {
+            if (it < nch) {
+                const int base = ((((d0 - 1) * a.H + (h0 - 1)) * a.W + (w0 - 1)) * a.ldx + (k0 + it) * 16) * 2;
+                const bf16* dst = lds + ((it & 1) * 4 + cw) * BUF;
+#pragma unroll
+                for (int i = 0; i < NCH; i++) {
+                    int off = zz[i] >= 0 ? base + rel[i] : OOBV;
+                    if (!interior && zz[i] >= 0) {
+                        const int gd = d0 - 1 + (zz[i] & 255), gh = h0 - 1 + ((zz[i] >> 8) & 255),
+                                  gw = w0 - 1 + ((zz[i] >> 16) & 255);
+                        if (!(gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)) off = OOBV;
+                    }
+                    ru3d_lds_dma16(rsrc, dst + i * 512, off);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer waves
+    const int co_blk = cg * (NT * 32);
+    const int ph = lane >> 5, wl = lane & 31;
+    const int rl = wl / TW, wv = wl % TW;
+    int xbm[MT][3];     // element offset (inside a buffer pair half) of this lane's piece: local tile m, W offset of the tap
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        const int gm = (m + wave) & 3;
+#pragma unroll
+        for (int tw = 0; tw < 3; tw++) {
+            const int zw = wv + tw;
+            xbm[m][tw] = ((((gm >> 1) * HH + (gm & 1) * R + rl) * WW) + zw) * 16 + ((ph ^ ((zw >> 2) & 1)) << 3) + wave * BUF;
+        }
+    }
+    const bf16x8* wbase = a.w + (int64_t)cg * NT * 64 + lane;
+    if (wave == 0) biasl[lane] = (a.bias && !a.part) ? a.bias[co_blk + lane] : 0.f;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[m][t][i] = 0.f;
+    bf16x8 wq[WD][NT];
+#pragma unroll
+    for (int s = 0; s < WD; s++) {
+        const int wtap = a.flip ? 26 - s : s;
+#pragma unroll
+        for (int t = 0; t < NT; t++) wq[s][t] = wbase[((int64_t)(wtap * KS + k0) * NTT + t) * 64];
+    }
+
+    for (int it = 0; it <= nch; it++) {
+        if (it >= 1) {
+            const int ch = it - 1;
+            const int chn = ch + 1 == nch ? ch : ch + 1;      // the last chunk's tail fetches stay inside the slice
+            const bf16* buf = lds + ((ch & 1) * 4) * BUF;
+            bf16x8 xq[XD][MT];
+#pragma unroll
+            for (int s = 0; s < XD; s++)
+#pragma unroll
+                for (int m = 0; m < MT; m++)
+                    xq[s][m] = *reinterpret_cast<const bf16x8*>(&buf[xbm[m][s % 3] + (((s / 9) * HH + (s / 3) % 3) * WW) * 16]);
+#pragma unroll
+            for (int s = 0; s < S; s++) {
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int m = 0; m < MT; m++)
+                        acc[m][t] = RU3D_MFMA_32X32X16(wq[s % WD][t], xq[s % XD][m], acc[m][t], 0, 0, 0);
+                if (s + XD < S) {
+                    const int s1 = s + XD;
+#pragma unroll
+                    for (int m = 0; m < MT; m++)
+                        xq[s % XD][m] =
+                            *reinterpret_cast<const bf16x8*>(&buf[xbm[m][s1 % 3] + (((s1 / 9) * HH + (s1 / 3) % 3) * WW) * 16]);
+                }
+                {
+                    const int s2 = s + WD < S ? s + WD : s + WD - S;
+                    const int c2 = s + WD < S ? ch : chn;
+                    const int wtap2 = a.flip ? 26 - s2 : s2;
+#pragma unroll
+                    for (int t = 0; t < NT; t++) wq[s % WD][t] = wbase[((int64_t)(wtap2 * KS + k0 + c2) * NTT + t) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+
+    // ---- exchange: every halo has been read (the barrier above), the buffers now carry accumulators.
+    // float4 slot [owner tile][source 0..2][t][q][lane]; a wave sends local tiles 1..3, which are tiles (m + wave) & 3
+    f32x4* red = reinterpret_cast<f32x4*>(lds);
+#pragma unroll
+    for (int m = 1; m < MT; m++) {
+        const int owner = (m + wave) & 3;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[i] = acc[m][t][q * 4 + i];
+                red[(((owner * 3 + (m - 1)) * NT + t) * 4 + q) * 64 + lane] = v;
+            }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int sl = 0; sl < 3; sl++)
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 v = red[(((wave * 3 + sl) * NT + t) * 4 + q) * 64 + lane];
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[0][t][q * 4 + i] += v[i];
+            }
+
+    // ---- epilogue of this wave's 32 voxels (tile `wave`)
+    const int od_w = d0 + (wave >> 1), hrow = h0 + (wave & 1) * R;
+    if (a.part) {
+        const int od = od_w, oh = hrow + rl, ow = w0 + wv;
+        if (od < a.D && oh < a.H && ow < a.W) {
+            const int64_t vox = (((int64_t)n * a.D + od) * a.H + oh) * a.W + ow;
+            float* pp = a.part + ((int64_t)bz * ((int64_t)a.N * a.D * a.H * a.W) + vox) * a.Cout;
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = acc[0][t][q * 4 + i];
+                    *reinterpret_cast<f32x4*>(pp + co_blk + t * 32 + 8 * q + 4 * ph) = v;
+                }
+        }
+        return;
+    }
+    bf16* est = patch[wave];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(&biasl[t * 32 + 8 * q + 4 * ph]);
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = acc[0][t][q * 4 + i] + bq[i];
+            store_vec<bf16, 4>(est + wl * MF_PITCH + 8 * q + 4 * ph, v);
+        }
+        const int part = lane & 3;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int row = (lane >> 2) + 16 * r;
+            const int od = od_w, oh = hrow + row / TW, ow = w0 + row % TW;
+            float v[8];
+            load_vec<bf16, 8>(est + row * MF_PITCH + part * 8, v);
+            if (od < a.D && oh < a.H && ow < a.W) {
+                const int64_t vox = (((int64_t)n * a.D + od) * a.H + oh) * a.W + ow;
+                const int c0 = co_blk + t * 32 + part * 8;
+                if (a.res) {
+                    float rr[8];
+                    load_vec<bf16, 8>(a.res + vox * a.ldr + c0, rr);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) v[i] += rr[i];
+                }
+                store_vec<bf16, 8>(a.y + vox * a.ldy + c0, v);
+            }
+        }
+    }
+}
+
+
 static void pc_grid(int cout, bool nt2, int64_t nblk, int* gx, int* gy) {
     *gy = cout / (nt2 ? 64 : 32);
     int g = 256 / *gy;                 // one persistent workgroup per CU in total
@@ -958,6 +1195,59 @@ static int s1_ksplit(const S1Plan& p, int N, int D, int H, int W, int Cin, int C
     return ks;
 }
 
+// the deep levels' in-workgroup split-K form (conv3_s1_sk_kernel): exact-fit tiles only
+struct SkPlan {
+    int tw, ks;
+    int64_t tiles;
+};
+
+static bool sk_plan(int N, int D, int H, int W, int Cin, int Cout, int ldx, SkPlan* p) {
+    static const int mode = getenv("RU3D_CONV_SK") ? atoi(getenv("RU3D_CONV_SK")) : 1;   // 0 = off
+    if (!mode) return false;
+    const int tw = (W % 16) == 0 ? 16 : ((W % 8) == 0 ? 8 : 0);
+    if (!tw) return false;
+    const int th = 64 / tw;
+    if ((D % 2) || (H % th) || (Cout % 64) || (Cin % 64) || ldx <= 0 || (ldx % 8)) return false;
+    if ((int64_t)D * H * W * ldx * 2 >= (1ll << 31)) return false;
+    const int64_t tiles = (int64_t)N * (D / 2) * (H / th) * (W / tw);
+    const int64_t units = tiles * (Cout / 64);
+    if (units > 512) return false;              // the large levels run on the persistent kernels
+    int ks = 1;
+    while (units * ks < 192 && ks < 8 && ((Cin / (ks * 2)) % 64) == 0) ks *= 2;
+    if (units * ks < 96) return false;
+    p->tw = tw;
+    p->ks = ks;
+    p->tiles = tiles;
+    return true;
+}
+
+static int launch_s1_sk(const MfmaConvArgs& a0, const SkPlan& sp, hipStream_t st) {
+    MfmaConvArgs a = a0;
+    const int th = 64 / sp.tw;
+    a.tiles_d = a.D / 2;
+    a.tiles_h = a.H / th;
+    a.tiles_w = a.W / sp.tw;
+    a.nblk = (int)sp.tiles;
+    a.ksplit = sp.ks;
+    a.part = sp.ks > 1 ? (float*)a.ws : nullptr;
+    dim3 grid((unsigned)(sp.tiles * (a.Cout / 64)), 1, sp.ks);
+    if (sp.tw == 16)
+        hipLaunchKernelGGL((conv3_s1_sk_kernel<16>), grid, dim3(512), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv3_s1_sk_kernel<8>), grid, dim3(512), 0, st, a);
+    int rc = ru3d_check_launch("conv3_s1_sk");
+    if (rc || sp.ks <= 1) return rc;
+    if (a.defer_ks) {        // the caller's next kernel sums the slices (norm_small.hip)
+        *a.defer_ks = sp.ks;
+        return 0;
+    }
+    const int64_t V = (int64_t)a.N * a.D * a.H * a.W;
+    const int64_t groups = V * (a.Cout / 8);
+    hipLaunchKernelGGL(conv_ksplit_reduce_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st,
+                       (const float*)a.part, sp.ks, V, a.Cout, a.bias, a.res, a.ldr, a.y, a.ldy);
+    return ru3d_check_launch("conv_ksplit_reduce");
+}
+
 // workspace a 3x3x3 stride-1 conv of this geometry can use (split-K partials); 0 = none needed
 size_t conv_mfma_ws_bytes(const ConvGeom& g) {
     if (!(g.k == 3 && g.stride == 1 && !g.transposed && (g.Cin % 32) == 0 && (g.Cout % 32) == 0)) return 0;
@@ -967,7 +1257,9 @@ size_t conv_mfma_ws_bytes(const ConvGeom& g) {
     if (const int wsl = conv_ws_slices(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout))
         return (size_t)wsl * g.N * g.Do * g.Ho * g.Wo * g.Cout * sizeof(float);
     const S1Plan p = s1_plan(g.N, g.Do, g.Ho, g.Wo, g.Cout, g.ldx);
-    const int ks = s1_ksplit(p, g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout);
+    int ks = s1_ksplit(p, g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout);
+    SkPlan sk;
+    if (p.small && sk_plan(g.N, g.Do, g.Ho, g.Wo, g.Cin, g.Cout, g.ldx, &sk) && sk.ks > ks) ks = sk.ks;
     return ks > 1 ? (size_t)ks * g.N * g.Do * g.Ho * g.Wo * g.Cout * sizeof(float) : 0;
 }
 
@@ -1000,6 +1292,16 @@ static int launch_s1_auto(const MfmaConvArgs& a, hipStream_t st) {
         if (p.wclass == 32) return launch_s1<2, 4, 32, 2>(a, p.nt2, st);
         if (p.wclass == 16) return launch_s1<2, 8, 16, 2>(a, p.nt2, st);
         return launch_s1<4, 8, 8, 2>(a, p.nt2, st);
+    }
+    // deep levels, exact-fit extents: 128-voxel x 64-cout blocks with the input channels split over the workgroup's waves
+    {
+        SkPlan sk;
+        if (!a.stat_slab && sk_plan(a.N, a.D, a.H, a.W, a.Cin, a.Cout, a.ldx, &sk)) {
+            const size_t bytes = (size_t)sk.ks * a.N * a.D * a.H * a.W * a.Cout * sizeof(float);
+            if (sk.ks == 1 || (a.ws && a.ws_bytes >= bytes && (((uintptr_t)a.ws) % 16) == 0 && (a.ldy % 8) == 0 &&
+                               (!a.res || (a.ldr % 8) == 0)))
+                return launch_s1_sk(a, sk, st);
+        }
     }
     // deep levels are bound by the weight bytes every workgroup pulls into its CU: when 256-voxel tiles x 32-cout
     // slices still give one workgroup per CU, they halve that traffic against the 128-voxel tiles

@@ -1,9 +1,12 @@
-"""The 512-voxel producer/consumer form of the 3x3x3 stride-1 conv (csrc/conv_mfma.hip conv3_s1_pc4_kernel; reference
+"""Two kernels with 4 x 2 accumulator tiles per wave.  (1) The 512-voxel producer/consumer form of the 3x3x3 stride-1 conv (csrc/conv_mfma.hip conv3_s1_pc4_kernel; reference
 network.py:394-416 at the 128-channel level of config 2 and the decoder's 128 -> 64 conv one level up): forward with bias
 and residual, fused InstanceNorm statistics, input gradient (flipped taps) against torch CPU on operands rounded to the
 storage type.  Every shape below satisfies the kernel's plan (D, H multiples of 4, width class 32, >= 192 workgroup
 units), so the default routing runs it (RU3D_CONV_PC4=0 sends them back to the 256-voxel kernel, which the ragged cases
-of tests/test_gpu_parity.py keep covering).  Run with `-m gpu`."""
+of tests/test_gpu_parity.py keep covering).
+(2) conv3_s1_sk_kernel, the deep levels' form (16^3 x 256, 8^3 x 512 channels): one 128-voxel x 64-cout block per workgroup,
+the input channels split over its four waves and, at 8^3, over workgroups too (fp32 partial slices + the fixed-order sum).
+Run with `-m gpu`."""
 import pytest
 import torch
 
@@ -27,6 +30,12 @@ SHAPES = [(2, 128, 128, (32, 32, 32)), (2, 64, 128, (16, 32, 56)), (3, 32, 64, (
           (1, 32, 64, (32, 48, 96))]
 
 
+# sk: config 2's two deep levels, the decoder's 512 -> 256 conv at 16^3, a 32-wide case on the 16-wide tile with a split
+# over workgroups, three samples with one 16-channel chunk per wave (ks = 4) on the 8-wide tile
+SK_SHAPES = [(2, 256, 256, (16, 16, 16)), (2, 512, 512, (8, 8, 8)), (2, 512, 256, (16, 16, 16)), (2, 256, 256, (8, 8, 32)),
+             (3, 256, 128, (4, 8, 24))]
+
+
 def _rt(t, dt):
     return t.to(dt).float()
 
@@ -41,9 +50,9 @@ def _close(a, b, rtol, atol, what):
 
 
 @pytest.mark.parametrize("dt", DTYPES, ids=["bf16", "fp16"])
-@pytest.mark.parametrize("n,cin,cout,dims", SHAPES)
+@pytest.mark.parametrize("n,cin,cout,dims", SHAPES + SK_SHAPES)
 def test_pc4_forward_bias_residual_and_dgrad(dt, n, cin, cout, dims):
-    if dt == torch.float16 and cin * cout > 128 * 128:
+    if dt == torch.float16 and cin * cout > 128 * 128 and dims[2] == 32 and dims[0] == 32:
         pytest.skip("the largest case runs once")
     g = torch.Generator().manual_seed(n + cin + cout + sum(dims))
     d, h, w = dims
