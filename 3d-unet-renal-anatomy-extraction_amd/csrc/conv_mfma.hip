@@ -1195,7 +1195,7 @@ static int s1_ksplit(const S1Plan& p, int N, int D, int H, int W, int Cin, int C
     return ks;
 }
 
-// the deep levels' in-workgroup split-K form (conv3_s1_sk_kernel): exact-fit tiles only
+// the deep levels' in-workgroup split-K form (conv3_s1_sk_kernel)
 struct SkPlan {
     int tw, ks;
     int64_t tiles;
@@ -1204,12 +1204,16 @@ struct SkPlan {
 static bool sk_plan(int N, int D, int H, int W, int Cin, int Cout, int ldx, SkPlan* p) {
     static const int mode = getenv("RU3D_CONV_SK") ? atoi(getenv("RU3D_CONV_SK")) : 1;   // 0 = off
     if (!mode) return false;
-    const int tw = (W % 16) == 0 ? 16 : ((W % 8) == 0 ? 8 : 0);
-    if (!tw) return false;
+    auto cdiv = [](int x, int y) { return (x + y - 1) / y; };
+    // tile width with the smaller padded volume (ties: the wider one); ragged extents are masked in the kernel
+    const int64_t v16 = (int64_t)cdiv(D, 2) * 2 * cdiv(H, 4) * 4 * cdiv(W, 16) * 16;
+    const int64_t v8 = (int64_t)cdiv(D, 2) * 2 * cdiv(H, 8) * 8 * cdiv(W, 8) * 8;
+    const int tw = v16 <= v8 ? 16 : 8;
     const int th = 64 / tw;
-    if ((D % 2) || (H % th) || (Cout % 64) || (Cin % 64) || ldx <= 0 || (ldx % 8)) return false;
+    if ((Cout % 64) || (Cin % 64) || ldx <= 0 || (ldx % 8)) return false;
     if ((int64_t)D * H * W * ldx * 2 >= (1ll << 31)) return false;
-    const int64_t tiles = (int64_t)N * (D / 2) * (H / th) * (W / tw);
+    if (mode < 2 && (int64_t)D * H * W * 10 < (tw == 16 ? v16 : v8) * 3) return false;   // under 30 % of the MFMAs useful
+    const int64_t tiles = (int64_t)N * cdiv(D, 2) * cdiv(H, th) * cdiv(W, tw);
     const int64_t units = tiles * (Cout / 64);
     if (units > 512) return false;              // the large levels run on the persistent kernels
     int ks = 1;
@@ -1224,9 +1228,9 @@ static bool sk_plan(int N, int D, int H, int W, int Cin, int Cout, int ldx, SkPl
 static int launch_s1_sk(const MfmaConvArgs& a0, const SkPlan& sp, hipStream_t st) {
     MfmaConvArgs a = a0;
     const int th = 64 / sp.tw;
-    a.tiles_d = a.D / 2;
-    a.tiles_h = a.H / th;
-    a.tiles_w = a.W / sp.tw;
+    a.tiles_d = (a.D + 1) / 2;
+    a.tiles_h = (a.H + th - 1) / th;
+    a.tiles_w = (a.W + sp.tw - 1) / sp.tw;
     a.nblk = (int)sp.tiles;
     a.ksplit = sp.ks;
     a.part = sp.ks > 1 ? (float*)a.ws : nullptr;

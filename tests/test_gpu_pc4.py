@@ -32,8 +32,9 @@ SHAPES = [(2, 128, 128, (32, 32, 32)), (2, 64, 128, (16, 32, 56)), (3, 32, 64, (
 
 # sk: config 2's two deep levels, the decoder's 512 -> 256 conv at 16^3, a 32-wide case on the 16-wide tile with a split
 # over workgroups, three samples with one 16-channel chunk per wave (ks = 4) on the 8-wide tile
+# ragged extents (masked tiles): config 4's 20 x 20 x 10 and 10 x 10 x 5 levels, an odd D with a 13-wide row
 SK_SHAPES = [(2, 256, 256, (16, 16, 16)), (2, 512, 512, (8, 8, 8)), (2, 512, 256, (16, 16, 16)), (2, 256, 256, (8, 8, 32)),
-             (3, 256, 128, (4, 8, 24))]
+             (3, 256, 128, (4, 8, 24)), (2, 256, 256, (20, 20, 10)), (2, 512, 512, (10, 10, 5)), (2, 128, 192, (7, 9, 13))]
 
 
 def _rt(t, dt):
