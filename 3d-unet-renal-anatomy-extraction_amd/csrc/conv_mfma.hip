@@ -263,13 +263,10 @@ __global__ __launch_bounds__(256, 2) void conv3_s1_mfma_kernel(MfmaConvArgs a) {
 //     skip the bounds checks.
 //   * work is dealt XCD-contiguously: the blocks that share an XCD walk a contiguous run of tiles, so the halo
 //     re-reads of neighbouring tiles meet in that XCD's L2.
-// MT = column tiles per consumer wave (tile = 128*MT voxels).  SWZ: unpadded 64-byte voxel pitch with the
-// 16-byte piece index XOR-ed by ((voxel >> 2) & 3) - conflict-free for 32-voxel W runs like the padded layout,
-// but 20 % smaller, which is what lets two 512-voxel halo buffers (MT = 4) fit in 160 KB.  MT = 4 halves the
-// weight-fragment traffic per MFMA (the L1/TA path saturates at 64 B/clk/CU) and the halo amplification.
-template <int TD, int TH, int TW, int MT, int NT, bool SWZ>
+// MT = column tiles per consumer wave (tile = 128*MT voxels); the 512-voxel form is conv3_s1_pc4_kernel below.
+template <int TD, int TH, int TW, int MT, int NT>
 __global__ __launch_bounds__(512, 2) void conv3_s1_pc_kernel(MfmaConvArgs a) {
-    constexpr int PITCH = SWZ ? 32 : MF_PITCH;
+    constexpr int PITCH = MF_PITCH;
     constexpr int HD = TD + 2, HH = TH + 2, WW = TW + 2;
     constexpr int HV = HD * HH * WW;
     // ring depths: ~700 cycles of MFMA work between a weight load and its use, ~2 MFMA groups for LDS reads
@@ -281,7 +278,7 @@ __global__ __launch_bounds__(512, 2) void conv3_s1_pc_kernel(MfmaConvArgs a) {
     static_assert((2 * HV * PITCH + 4 * MT * 32 * MF_PITCH) * 2 <= 160 * 1024, "two halo buffers must fit in LDS");
     __shared__ __attribute__((aligned(16))) bf16 lds[2 * HV * PITCH + 4 * MT * 32 * MF_PITCH];   // 2 halo buffers + epilogue patches
     // element offset of 16-byte piece `p` of halo voxel `hv`
-    auto piece_off = [](int hv, int p) { return SWZ ? hv * 32 + ((p ^ ((hv >> 2) & 3)) << 3) : hv * MF_PITCH + (p << 3); };
+    auto piece_off = [](int hv, int p) { return hv * MF_PITCH + (p << 3); };
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1036,7 +1033,7 @@ static void pc_grid(int cout, bool nt2, int64_t nblk, int* gx, int* gy) {
     *gx = g;
 }
 
-template <int TD, int TH, int TW, int MT, bool SWZ>
+template <int TD, int TH, int TW, int MT>
 static int launch_s1_pc(const MfmaConvArgs& a0, bool nt2, hipStream_t st) {
     MfmaConvArgs a = a0;
     a.tiles_d = (a.D + TD - 1) / TD;
@@ -1049,9 +1046,9 @@ static int launch_s1_pc(const MfmaConvArgs& a0, bool nt2, hipStream_t st) {
     pc_grid(a.Cout, nt2, nblk, &gx, &gy);
     dim3 grid(gx, gy);
     if (nt2)
-        hipLaunchKernelGGL((conv3_s1_pc_kernel<TD, TH, TW, MT, 2, SWZ>), grid, dim3(512), 0, st, a);
+        hipLaunchKernelGGL((conv3_s1_pc_kernel<TD, TH, TW, MT, 2>), grid, dim3(512), 0, st, a);
     else
-        hipLaunchKernelGGL((conv3_s1_pc_kernel<TD, TH, TW, MT, 1, SWZ>), grid, dim3(512), 0, st, a);
+        hipLaunchKernelGGL((conv3_s1_pc_kernel<TD, TH, TW, MT, 1>), grid, dim3(512), 0, st, a);
     return ru3d_check_launch("conv3_s1_pc");
 }
 
@@ -1290,9 +1287,9 @@ static int launch_s1_auto(const MfmaConvArgs& a, hipStream_t st) {
     if (a.stat_slab && !p.pc) return ru3d_fail(-1, "conv_mfma: fused statistics need the producer/consumer kernel");
     if (!p.small) {
         if (p.pc4) return launch_s1_pc4(a, st);
-        if (p.pc && p.wclass == 32) return launch_s1_pc<2, 4, 32, 2, false>(a, p.nt2, st);
-        if (p.pc && p.wclass == 16) return launch_s1_pc<2, 8, 16, 2, false>(a, p.nt2, st);
-        if (p.pc && p.wclass == 8) return launch_s1_pc<4, 8, 8, 2, false>(a, p.nt2, st);
+        if (p.pc && p.wclass == 32) return launch_s1_pc<2, 4, 32, 2>(a, p.nt2, st);
+        if (p.pc && p.wclass == 16) return launch_s1_pc<2, 8, 16, 2>(a, p.nt2, st);
+        if (p.pc && p.wclass == 8) return launch_s1_pc<4, 8, 8, 2>(a, p.nt2, st);
         if (p.wclass == 32) return launch_s1<2, 4, 32, 2>(a, p.nt2, st);
         if (p.wclass == 16) return launch_s1<2, 8, 16, 2>(a, p.nt2, st);
         return launch_s1<4, 8, 8, 2>(a, p.nt2, st);

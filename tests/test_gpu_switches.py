@@ -25,7 +25,8 @@ SWITCHES = {
            {"RU3D_CONV_WS": "2", "RU3D_STEM_MFMA": "0", "RU3D_HEAD_FUSED": "0"},         # whole-sample conv, VALU stem, unfused head backward
            {"RU3D_SKIP_LINK": "0", "RU3D_WGRAD_DIRECT": "0", "RU3D_WGRAD_STREAM": "0"},  # concat copies, slabs at 8^3, one stream
            # round 4: norm.hip's three launches on the small levels, the interleaved concat on the full-resolution level
-           {"RU3D_IN_SMALL": "0", "RU3D_PLANAR_CONCAT": "0"}],
+           # ... and the deep levels on the 1 x 2-accumulator conv kernel instead of the split-in-workgroup one
+           {"RU3D_IN_SMALL": "0", "RU3D_PLANAR_CONCAT": "0", "RU3D_CONV_SK": "0"}],
     "c4": [{"RU3D_CONV_TILEFIT": "0", "RU3D_SLIDE64_EDGE": "0", "RU3D_CONV_WS": "0"},    # round-2 tilings of the odd extents
            {"RU3D_PAD_CHANNELS": "0"}],                                                   # F = 30 on the generic kernels
 }
