@@ -213,7 +213,17 @@ def main():
 
     import torch
     one_device = os.environ.get("RU3D_ONE_DEVICE") == "1"
-    if world > 1:
+    # RU3D_DP_REHEARSE=1 at N = 1: the data-parallel machinery of N > 1 (GradSync: buckets in autograd order, gradients born
+    # inside them, RCCL all-reduce per bucket on the side stream - with a communicator of one rank -, fused Adam on the
+    # aliased buckets, the eager loop) on the one GPU there is: what the N > 1 host path and its extra launches cost
+    rehearse = world == 1 and os.environ.get("RU3D_DP_REHEARSE") == "1"
+    if rehearse:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    elif world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # torch.distributed = rendezvous + control plane (store, barrier, the max over ranks of the timing) on gloo;
@@ -242,7 +252,7 @@ def main():
     model.train(not args.eval_mode)
     sync = None
     transport = None
-    if world > 1:
+    if world > 1 or rehearse:
         from parallel import make_grad_sync, broadcast_parameters
         broadcast_parameters(model)
         want = os.environ.get("RU3D_COMM", "torch" if one_device else "rccl")
@@ -298,7 +308,7 @@ def main():
     # for bit (graph.py, tests/test_gpu_graph.py).  Round 2 measured the eager loop within 5 % of host-bound (17.5 ms of
     # enqueueing per 18.4 ms step); every kernel saving since then would otherwise disappear behind the interpreter.
     # The eager figure of the same steps rides along (`ms_per_step_eager`); `--launch eager` times that loop alone.
-    use_graph = args.launch in ("auto", "graph") and world == 1 and args.optimizer == "fused"
+    use_graph = args.launch in ("auto", "graph") and world == 1 and not rehearse and args.optimizer == "fused"
     gstep = None
 
     def fence():
@@ -389,7 +399,9 @@ def main():
     if use_graph:
         out["ms_per_step_eager"] = eager_ms
         out["host_enqueue_ms_per_step_eager"] = eager_host_ms
-    if world > 1:
+    if rehearse:
+        out["config"]["rehearsal"] = "RU3D_DP_REHEARSE=1: N > 1 host path (GradSync + eager loop) with a communicator of one rank"
+    if world > 1 or rehearse:
         out["config"]["grad_exchange"] = ("RCCL all-reduce via ru3d_comm_allreduce, side HIP stream, 64 MiB buckets, "
                                           "%s transport" % args.grad_transport) if transport == "rccl" else \
             "torch.distributed (%s)" % dist.get_backend()
@@ -472,7 +484,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or rehearse:
         if sync is not None:
             torch.cuda.synchronize()
             sync.remove()
