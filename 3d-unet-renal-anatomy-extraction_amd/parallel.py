@@ -32,6 +32,7 @@ Design (MI355X: 7 xGMI links per GPU, point-to-point):
 """
 import ctypes
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -69,9 +70,19 @@ class RcclComm:
         else:
             N.check(N.lib.ru3d_comm_unique_id(ctypes.cast(blob, ctypes.c_void_p)), "comm_unique_id")
         handle = ctypes.c_void_p()
-        N.check(N.lib.ru3d_comm_init(ctypes.byref(handle), ctypes.cast(blob, ctypes.c_void_p), world, rank,
-                                     self.device.index if self.device.index is not None else
-                                     torch.cuda.current_device()), "comm_init")
+        # RCCL prints its version banner to STDOUT when the first communicator comes up: a program whose stdout is a
+        # protocol (bench.py: one JSON line) would carry it; the banner goes to stderr for the duration of the call
+        sys.stdout.flush()
+        saved = os.dup(1)
+        try:
+            os.dup2(2, 1)
+            rc = N.lib.ru3d_comm_init(ctypes.byref(handle), ctypes.cast(blob, ctypes.c_void_p), world, rank,
+                                      self.device.index if self.device.index is not None else
+                                      torch.cuda.current_device())
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        N.check(rc, "comm_init")
         self.handle = handle
 
     def allreduce(self, flat, average, stream):

@@ -198,6 +198,22 @@ def parity_report(args, model, dims, dev, dtype):
     return out
 
 
+class _StdoutToStderr:
+    """gloo and RCCL announce themselves on STDOUT (C++ side); bench.py's stdout is one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "0") or 0)
@@ -222,7 +238,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         torch.cuda.set_device(0)
-        dist.init_process_group("gloo", rank=0, world_size=1)
+        with _StdoutToStderr():
+            dist.init_process_group("gloo", rank=0, world_size=1)
     elif world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -233,7 +250,8 @@ def main():
         if one_device:
             local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("gloo")
+        with _StdoutToStderr():
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local if world > 1 else 0)
@@ -259,7 +277,8 @@ def main():
         gd = torch.bfloat16 if (args.grad_transport == "bf16" and want == "rccl") else torch.float32
         # every rank votes on the transport before any of them enters RCCL's collective set-up, and again on its outcome
         # (parallel.make_grad_sync): either all ranks exchange over RCCL or all over torch.distributed
-        sync = make_grad_sync(model, transport=want, grad_dtype=gd, exchange=os.environ.get("RU3D_EXCHANGE", "allreduce"))
+        with _StdoutToStderr():
+            sync = make_grad_sync(model, transport=want, grad_dtype=gd, exchange=os.environ.get("RU3D_EXCHANGE", "allreduce"))
         transport = sync.transport
         if transport != want and rank == 0:
             print("bench.py: RCCL exchange unavailable on some rank (%s); all ranks use torch.distributed" %
