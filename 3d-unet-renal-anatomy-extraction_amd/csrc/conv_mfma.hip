@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(512, 2) void conv3_s1_sk_kernel(MfmaConvArgs a) {
 
 static void pc_grid(int cout, bool nt2, int64_t nblk, int* gx, int* gy) {
     *gy = cout / (nt2 ? 64 : 32);
-    int g = 256 / *gy;                 // one persistent workgroup per CU in total
+    int g = ru3d_get_cu_budget() / *gy;   // one persistent workgroup per CU in total (N > 1: minus the CUs left to RCCL)
     g = g < 8 ? 8 : (g / 8) * 8;        // multiple of 8 so that blockIdx.x % 8 is the XCD label for every y
     if (g > nblk) g = (int)nblk;
     *gx = g;
@@ -1170,7 +1170,7 @@ static S1Plan s1_plan(int N, int D, int H, int W, int Cout, int ldx) {
     if (p.pc && p.nt2 && p.wclass == 32 && pc4_mode && (D % 4) == 0 && (H % 4) == 0 && ldx > 0 && (ldx % 8) == 0) {
         const int64_t n4 = (int64_t)N * (D / 4) * (H / 4) * cdiv(W, 32);
         const int64_t sample_bytes = (int64_t)D * H * W * ldx * 2;
-        if (n4 * (Cout / 64) >= 192 && sample_bytes < (1ll << 31)) {
+        if (n4 * (Cout / 64) * 4 >= (int64_t)ru3d_get_cu_budget() * 3 && sample_bytes < (1ll << 31)) {
             p.pc4 = true;
             p.nblk_pc = n4;
         }

@@ -96,3 +96,27 @@ def test_pc4_fused_instance_norm_statistics(dt, n, cin, cout, dims):
     v = yd.var(dim=(2, 3, 4), unbiased=False).reshape(-1)
     _close(mean, m, 1e-5, 2e-5, "mean")
     _close(scale, 1.0 / (v + 1e-5).sqrt(), 2e-5, 1e-6, "scale")
+
+
+def test_pc4_with_a_reduced_cu_budget():
+    """N > 1 leaves CUs to RCCL (ru3d_set_cu_budget): the persistent grid shrinks, several tiles per workgroup, the
+    statistics slab follows the grid - same result as with the whole chip."""
+    n, cin, cout, dims = SHAPES[0]
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(99)
+    d, h, w = dims
+    xv = torch.randn(n, cin, d, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, 3, generator=g) * (1.0 / (27 * cin) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    x = ops.as_input(xv.to(DEV), dt)
+    pw = ops.pack_weight(wt.to(DEV), N.ROLE_CONV_FWD, dt, 1)
+    y0, m0, s0 = ops.conv_fwd_in(x, pw, b.to(DEV), cout, 3, 1)
+    assert N.lib.ru3d_set_cu_budget(208) == 0
+    try:
+        y1, m1, s1 = ops.conv_fwd_in(x, pw, b.to(DEV), cout, 3, 1)
+        torch.cuda.synchronize()
+    finally:
+        assert N.lib.ru3d_set_cu_budget(0) == 0
+    assert torch.equal(y0, y1)
+    _close(m1, m0, 1e-6, 1e-6, "mean under a reduced budget")
+    _close(s1, s0, 1e-6, 1e-6, "scale under a reduced budget")
