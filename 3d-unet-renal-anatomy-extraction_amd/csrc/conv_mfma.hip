@@ -1641,7 +1641,7 @@ __global__ __launch_bounds__(256) void conv_direct_mfma_kernel(DirectArgs a) {
 // 16 zero bytes in the code object's data segment: out-of-range lanes load them instead of branching
 __device__ __attribute__((aligned(16))) bf16 g_zero16[8];
 
-template <int NT>
+template <int NT, int RD>
 __global__ __launch_bounds__(256) void conv_gather_mfma_kernel(DirectArgs a) {
     const bf16* const zero16 = g_zero16;
     __shared__ __attribute__((aligned(16))) float patch_s[4][32 * (NT * 32 + 4)];
@@ -1689,38 +1689,57 @@ __global__ __launch_bounds__(256) void conv_gather_mfma_kernel(DirectArgs a) {
             for (int i = 0; i < 16; i++) acc[m][t][i] = 0.f;
 
     const int T = taps * KS;
-    auto fetch = [&](int j, bf16x8 (&xb)[2], bf16x8 (&wa)[NT]) {
-        const int tap = j / KS, ks = j - tap * KS;                     // wave-uniform
-        const int kw = tap % a.k, kh = (tap / a.k) % a.k, kd = tap / (a.k * a.k);
-        const int64_t delta = (((int64_t)kd * a.Hi + kh) * a.Wi + kw) * a.ldx + ks * 16;
-        const int wtap = a.flip ? taps - 1 - tap : tap;
+    // RD iterations of fragments in flight (one iteration of prefetch until round 4: every iteration then waited ~500
+    // cycles for its L2 hits behind 128 cycles of MFMA - 216 iterations x 0.25 us were the 54 us of the 128 -> 256 conv at
+    // 32^3).  The (tap, k-step) counters advance with the fetches (wave-uniform, no division in the loop); iterations past
+    // T load the zero block and the last weight fragment again, so the ring body has no branch and the waits stay counted.
+    // RD = 6 for the 3x3x3 forms; the 1x1x1 forms (4-32 iterations, HBM-bound on the large levels) keep RD = 2.
+    int f_j = 0, f_tap = 0, f_ks = 0, f_kw = 0, f_kh = 0, f_kd = 0;
+    auto fetch = [&](bf16x8 (&xb)[2], bf16x8 (&wa)[NT]) {
+        const bool live = f_j < T;
+        const int64_t delta = (((int64_t)f_kd * a.Hi + f_kh) * a.Wi + f_kw) * a.ldx + f_ks * 16;
+        const int wtap = a.flip ? taps - 1 - f_tap : f_tap;
 #pragma unroll
         for (int m = 0; m < 2; m++) {
-            const bf16* p = ((mask[m] >> tap) & 1u) ? xbase[m] + delta : zero16;
+            const bf16* p = (live && ((mask[m] >> f_tap) & 1u)) ? xbase[m] + delta : zero16;
             xb[m] = *reinterpret_cast<const bf16x8*>(p);
         }
-        const bf16x8* wrow = a.w + (((int64_t)wtap * KS + ks) * NTT + blockIdx.y * NT) * 64 + lane;
+        const bf16x8* wrow = a.w + (((int64_t)wtap * KS + f_ks) * NTT + blockIdx.y * NT) * 64 + lane;
 #pragma unroll
         for (int t = 0; t < NT; t++) wa[t] = wrow[t * 64];
-    };
-    auto compute = [&](const bf16x8 (&xb)[2], const bf16x8 (&wa)[NT]) {
-#pragma unroll
-        for (int t = 0; t < NT; t++)
-#pragma unroll
-            for (int m = 0; m < 2; m++)
-                acc[m][t] = RU3D_MFMA_32X32X16(wa[t], xb[m], acc[m][t], 0, 0, 0);
+        if (f_j + 1 < T) {
+            f_ks++;
+            if (f_ks == KS) {
+                f_ks = 0;
+                f_tap++;
+                f_kw++;
+                if (f_kw == a.k) {
+                    f_kw = 0;
+                    f_kh++;
+                    if (f_kh == a.k) {
+                        f_kh = 0;
+                        f_kd++;
+                    }
+                }
+            }
+        }
+        f_j++;
     };
     {
-        bf16x8 x0[2], x1[2], w0[NT], w1[NT];
-        fetch(0, x0, w0);
-        int j = 0;
-        for (; j + 1 < T; j += 2) {
-            fetch(j + 1, x1, w1);
-            compute(x0, w0);
-            if (j + 2 < T) fetch(j + 2, x0, w0);
-            compute(x1, w1);
+        bf16x8 xr[RD][2], wr[RD][NT];
+#pragma unroll
+        for (int r = 0; r < RD; r++) fetch(xr[r], wr[r]);
+        for (int j = 0; j < T; j += RD) {
+#pragma unroll
+            for (int r = 0; r < RD; r++) {
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int m = 0; m < 2; m++)
+                        acc[m][t] = RU3D_MFMA_32X32X16(wr[r][t], xr[r][m], acc[m][t], 0, 0, 0);
+                fetch(xr[r], wr[r]);
+            }
         }
-        if (j < T) compute(x0, w0);
     }
 
     if (a.rows16) {
@@ -1772,7 +1791,7 @@ __global__ __launch_bounds__(256) void conv_gather_mfma_kernel(DirectArgs a) {
 // 32-voxel column tile (transposed form: 32 half-resolution positions of one parity class, blockIdx.z) x NT cout
 // tiles, its 4 waves split the (tap, k-step) iterations, every wave keeps the next iteration's fragments in flight,
 // and the four partial tiles are summed through LDS in a fixed order before the fused bias / residual / store.
-template <int NT, bool TRANSPOSED>
+template <int NT, bool TRANSPOSED, int RD>
 __global__ __launch_bounds__(256) void conv_direct_ksplit_kernel(DirectArgs a) {
     __shared__ float red[4][NT][64][17];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1835,13 +1854,26 @@ __global__ __launch_bounds__(256) void conv_direct_ksplit_kernel(DirectArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
 
-    auto fetch = [&](int j, bf16x8& xb, bf16x8 (&wa)[NT]) {
-        const int ks = j % KS;
-        int tq = j / KS;
-        const int kw = k0w + kstep * (tq % nkw);
+    // Fragments of iteration j: the (tap, k-step) counters advance with j (wave-uniform: scalar unit), no divisions in the
+    // loop.  An iteration past the end re-reads the last valid one with a zero activation fragment (its MFMAs add zero): the
+    // ring below then has no branch in its body and the compiler's vmcnt waits stay counted.
+    // The ring is RD iterations deep: with one iteration of prefetch (rounds 1-3) every step waited ~500 cycles for an L2
+    // hit behind 64 cycles of MFMA - 108 steps x 0.4 us were the whole 45-58 us of these launches.  RD = 8 for the 3x3x3
+    // forms, 2 for the 1x1x1 forms (4-8 iterations per wave: a deeper ring would be mostly padding).
+    int f_ks, f_kw, f_kh, f_kd, f_j;         // state of the NEXT fetch
+    {
+        f_j = j_lo;
+        f_ks = j_lo % KS;
+        int tq = j_lo / KS;
+        f_kw = tq % nkw;
         tq /= nkw;
-        const int kh = k0h + kstep * (tq % nkh);
-        const int kd = k0d + kstep * (tq / nkh);
+        f_kh = tq % nkh;
+        f_kd = tq / nkh;
+    }
+    auto fetch = [&](bf16x8& xb, bf16x8 (&wa)[NT]) {
+        const bool live = f_j < j_hi;
+        const int ks = f_ks;
+        const int kw = k0w + kstep * f_kw, kh = k0h + kstep * f_kh, kd = k0d + kstep * f_kd;
         int id, ih, iw;
         if (TRANSPOSED) {
             id = ba + (((cl >> 2) + a.pad - kd) >> 1);
@@ -1854,32 +1886,44 @@ __global__ __launch_bounds__(256) void conv_direct_ksplit_kernel(DirectArgs a) {
         }
         const int tap = (kd * a.k + kh) * a.k + kw;
         const int wtap = a.flip ? taps - 1 - tap : tap;
-        const bool inb = valid && id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
-        const bf16* xp = a.x + ((((int64_t)n_ * a.Di + (inb ? id : 0)) * a.Hi + (inb ? ih : 0)) * a.Wi + (inb ? iw : 0)) * a.ldx +
-                         (lane >> 5) * 8 + ks * 16;
-        const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-        const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xp);   // always a valid address; zeroed below
-        xb = inb ? xv : z8;
+        const bool inb = live && valid && id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi;
+        // out-of-range lanes load a 16-byte zero block: no select behind the load (the compiler gathered such selects at
+        // the top of the unrolled ring body, i.e. waited for the youngest load there)
+        const bf16* xp = inb ? a.x + ((((int64_t)n_ * a.Di + id) * a.Hi + ih) * a.Wi + iw) * a.ldx + (lane >> 5) * 8 + ks * 16
+                             : (const bf16*)g_zero16;
+        xb = *reinterpret_cast<const bf16x8*>(xp);
         const bf16x8* wrow = a.w + (((int64_t)wtap * KS + ks) * NTT + blockIdx.y * NT) * 64 + lane;
 #pragma unroll
         for (int t = 0; t < NT; t++) wa[t] = wrow[t * 64];
+        if (live && f_j + 1 < j_hi) {         // advance (the last valid iteration is kept for the padding fetches)
+            f_ks++;
+            if (f_ks == KS) {
+                f_ks = 0;
+                f_kw++;
+                if (f_kw == nkw) {
+                    f_kw = 0;
+                    f_kh++;
+                    if (f_kh == nkh) {
+                        f_kh = 0;
+                        f_kd++;
+                    }
+                }
+            }
+        }
+        f_j++;
     };
 
     if (j_lo < j_hi) {
-        bf16x8 xb0, xb1, wa0[NT], wa1[NT];
-        fetch(j_lo, xb0, wa0);
-        int j = j_lo;
-        for (; j + 1 < j_hi; j += 2) {
-            fetch(j + 1, xb1, wa1);
+        bf16x8 xb[RD], wa[RD][NT];
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = RU3D_MFMA_32X32X16(wa0[t], xb0, acc[t], 0, 0, 0);
-            if (j + 2 < j_hi) fetch(j + 2, xb0, wa0);
+        for (int r = 0; r < RD; r++) fetch(xb[r], wa[r]);
+        for (int j = j_lo; j < j_hi; j += RD) {
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = RU3D_MFMA_32X32X16(wa1[t], xb1, acc[t], 0, 0, 0);
-        }
-        if (j < j_hi) {
+            for (int r = 0; r < RD; r++) {
 #pragma unroll
-            for (int t = 0; t < NT; t++) acc[t] = RU3D_MFMA_32X32X16(wa0[t], xb0, acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; t++) acc[t] = RU3D_MFMA_32X32X16(wa[r][t], xb[r], acc[t], 0, 0, 0);
+                fetch(xb[r], wa[r]);
+            }
         }
     }
 #pragma unroll
@@ -2055,7 +2099,37 @@ __global__ __launch_bounds__(256, 2) void convt_tile_mfma_kernel(DirectArgs a) {
                 for (int tt = 0; tt < NT; tt++)
                     acc[m][tt] = RU3D_MFMA_32X32X16(wa[tt], xb[m], acc[m][tt], 0, 0, 0);
         };
-        {
+        constexpr int RD = 4;
+        if ((T % RD) == 0) {
+            // weight fragments RD iterations ahead (one until round 4: an L2 hit takes longer than the 4-8 MFMAs of an
+            // iteration), activation fragments of the next iteration read from LDS in front of this iteration's MFMAs;
+            // the fetches past the end repeat the last iteration's (branch-free body, counted waits)
+            bf16x8 wq[RD][NT], xq[2][MT];
+            int ro[RD];
+            int fj = 0;
+            auto wnext = [&](bf16x8 (&wa)[NT], int& roff) {
+                wfetch(fj < T ? fj : T - 1, wa, roff);
+                fj++;
+            };
+#pragma unroll
+            for (int r = 0; r < RD; r++) wnext(wq[r], ro[r]);
+#pragma unroll
+            for (int m = 0; m < MT; m++) xq[0][m] = *reinterpret_cast<const bf16x8*>(tile_lds + rowm[m] + ro[0]);
+            for (int j = 0; j < T; j += RD) {
+#pragma unroll
+                for (int r = 0; r < RD; r++) {
+#pragma unroll
+                    for (int m = 0; m < MT; m++)
+                        xq[(r + 1) & 1][m] = *reinterpret_cast<const bf16x8*>(tile_lds + rowm[m] + ro[(r + 1) % RD]);
+#pragma unroll
+                    for (int m = 0; m < MT; m++)
+#pragma unroll
+                        for (int tt = 0; tt < NT; tt++)
+                            acc[m][tt] = RU3D_MFMA_32X32X16(wq[r][tt], xq[r & 1][m], acc[m][tt], 0, 0, 0);
+                    wnext(wq[r], ro[r]);
+                }
+            }
+        } else {
             bf16x8 w0[NT], w1[NT];
             int r0, r1;
             wfetch(0, w0, r0);
@@ -2159,13 +2233,16 @@ static int launch_direct(const void* x, const void* w, const float* bias, const 
         // few, long workgroups: split the reduction over the waves of 32-voxel workgroups instead
         const int64_t tiles = (a.total + 31) / 32;
         dim3 gk((unsigned)tiles, g.Cout / (nt2 ? 64 : 32), g.transposed ? 8 : 1);
+        const bool deep = g.k >= 3;
+#define RU3D_KSPLIT_LAUNCH(NTV, TRV)                                                                              \
+    if (deep) hipLaunchKernelGGL((conv_direct_ksplit_kernel<NTV, TRV, 8>), gk, dim3(256), 0, st, a);             \
+    else hipLaunchKernelGGL((conv_direct_ksplit_kernel<NTV, TRV, 2>), gk, dim3(256), 0, st, a)
         if (g.transposed) {
-            if (nt2) hipLaunchKernelGGL((conv_direct_ksplit_kernel<2, true>), gk, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((conv_direct_ksplit_kernel<1, true>), gk, dim3(256), 0, st, a);
+            if (nt2) { RU3D_KSPLIT_LAUNCH(2, true); } else { RU3D_KSPLIT_LAUNCH(1, true); }
         } else {
-            if (nt2) hipLaunchKernelGGL((conv_direct_ksplit_kernel<2, false>), gk, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((conv_direct_ksplit_kernel<1, false>), gk, dim3(256), 0, st, a);
+            if (nt2) { RU3D_KSPLIT_LAUNCH(2, false); } else { RU3D_KSPLIT_LAUNCH(1, false); }
         }
+#undef RU3D_KSPLIT_LAUNCH
         return ru3d_check_launch("conv_direct_ksplit");
     }
     static const int tile_mode = getenv("RU3D_CONVT_TILE") ? atoi(getenv("RU3D_CONVT_TILE")) : 1;
@@ -2178,13 +2255,22 @@ static int launch_direct(const void* x, const void* w, const float* bias, const 
             return nt2 ? launch_convt_tile<2, 2, 2, 32>(a, g.N, st) : launch_convt_tile<1, 2, 2, 32>(a, g.N, st);
         }
         if (a.hw >= 12 && g.Cin <= 256) {
-            return nt2 ? launch_convt_tile<2, 2, 4, 16>(a, g.N, st) : launch_convt_tile<1, 2, 4, 16>(a, g.N, st);
+            // 64-cout workgroups only when they still fill the chip (16^3 -> 32^3 at N = 2: 64 tiles)
+            static const int nt_mode = getenv("RU3D_CONVT_NT") ? atoi(getenv("RU3D_CONVT_NT")) : 1;
+            const int64_t t16 = (int64_t)g.N * ((a.hd + 1) / 2) * ((a.hh + 3) / 4) * ((a.hw + 15) / 16);
+            const bool wide = nt2 && (nt_mode == 0 || t16 * (g.Cout / 64) >= 200);
+            return wide ? launch_convt_tile<2, 2, 4, 16>(a, g.N, st) : launch_convt_tile<1, 2, 4, 16>(a, g.N, st);
         }
     }
     dim3 grid((unsigned)nblk, g.Cout / (nt2 ? 64 : 32));
     if (!g.transposed && g.k * g.k * g.k <= 27) {
-        if (nt2) hipLaunchKernelGGL((conv_gather_mfma_kernel<2>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((conv_gather_mfma_kernel<1>), grid, dim3(256), 0, st, a);
+        if (g.k >= 3) {
+            if (nt2) hipLaunchKernelGGL((conv_gather_mfma_kernel<2, 6>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_gather_mfma_kernel<1, 6>), grid, dim3(256), 0, st, a);
+        } else {
+            if (nt2) hipLaunchKernelGGL((conv_gather_mfma_kernel<2, 2>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((conv_gather_mfma_kernel<1, 2>), grid, dim3(256), 0, st, a);
+        }
         return ru3d_check_launch("conv_gather_mfma");
     }
     if (!g.transposed) return ru3d_fail(-1, "conv_direct_mfma: no gather kernel for k = %d", g.k);

@@ -1,4 +1,4 @@
-"""Micro-benchmark of the stride-2 / transposed / 1x1x1 conv forms at the two top level boundaries of config 2 (bf16):
+"""Micro-benchmark of the stride-2 / transposed / 1x1x1 conv forms at the four level boundaries of config 2 (bf16):
     python tools/kbench_direct.py [filter]
 Prints microseconds per launch and the algorithmic bytes (|in| + |out| [+ |res|]) per second."""
 import os, sys
@@ -29,7 +29,7 @@ def report(name, us, nbytes):
     print("%-46s %8.1f us  %6.0f GB/s alg  (%4.1f%% of 8 TB/s)" % (name, us, nbytes / us / 1e3, nbytes / us / 1e3 / 80), flush=True)
 
 
-for lvl, (c, s) in enumerate([(32, 128), (64, 64)]):
+for lvl, (c, s) in enumerate([(32, 128), (64, 64), (128, 32), (256, 16)]):
     n = 2
     tag = "L%d%d " % (lvl, lvl + 1)
     xb = act(n, c, s)              # big side, C channels
