@@ -14,6 +14,8 @@
 #include "common.h"
 #include "conv.h"
 
+#include <type_traits>
+
 namespace RU3D_NS {
 
 #define MF_PITCH 40  // bf16 elements per staged voxel (32 data + 8 pad) = 80 bytes
@@ -2099,11 +2101,11 @@ __global__ __launch_bounds__(256, 2) void convt_tile_mfma_kernel(DirectArgs a) {
                 for (int tt = 0; tt < NT; tt++)
                     acc[m][tt] = RU3D_MFMA_32X32X16(wa[tt], xb[m], acc[m][tt], 0, 0, 0);
         };
-        constexpr int RD = 4;
-        if ((T % RD) == 0) {
-            // weight fragments RD iterations ahead (one until round 4: an L2 hit takes longer than the 4-8 MFMAs of an
-            // iteration), activation fragments of the next iteration read from LDS in front of this iteration's MFMAs;
-            // the fetches past the end repeat the last iteration's (branch-free body, counted waits)
+        // weight fragments RD iterations ahead (one until round 4: an L2 hit takes longer than the 4-8 MFMAs of an
+        // iteration), activation fragments of the next iteration read from LDS in front of this iteration's MFMAs;
+        // the fetches past the end repeat the last iteration's (branch-free body, counted waits)
+        auto ring = [&](auto rd_tag) {
+            constexpr int RD = decltype(rd_tag)::value;
             bf16x8 wq[RD][NT], xq[2][MT];
             int ro[RD];
             int fj = 0;
@@ -2129,6 +2131,10 @@ __global__ __launch_bounds__(256, 2) void convt_tile_mfma_kernel(DirectArgs a) {
                     wnext(wq[r], ro[r]);
                 }
             }
+        };
+        // (8 deep for the 4-MFMA iterations of the NT = 1 forms: 56 vs 54-55 us - no better)
+        if ((T % 4) == 0) {
+            ring(std::integral_constant<int, 4>{});
         } else {
             bf16x8 w0[NT], w1[NT];
             int r0, r1;
