@@ -26,6 +26,8 @@ wall = t1 - t0
 print("steps %d  kernels/step %.1f  wall %.3f ms/step  busy %.3f  idle %.3f  >=2 kernels in flight %.3f  sum of durations %.3f" % (
     steps, len(win) / steps, wall / 1e6 / steps, busy / 1e6 / steps, (wall - busy) / 1e6 / steps, multi / 1e6 / steps,
     sum(r[1] - r[0] for r in win) / 1e6 / steps))
+short = [r for r in win if r[1] - r[0] < 12000]
+print("kernels shorter than 12 us: %.1f per step, %.3f ms per step" % (len(short) / steps, sum(r[1] - r[0] for r in short) / 1e6 / steps))
 q = {}
 for r in win: q[r[3]] = q.get(r[3], 0) + r[1] - r[0]
 print("busy per queue (ms/step):", {k: round(v / 1e6 / steps, 3) for k, v in q.items()})
