@@ -168,6 +168,9 @@ struct WgradSlidePlan {
 bool wgrad_slide_plan(const WgradGeom& g, WgradSlidePlan* out);
 size_t wgrad_slide_ws_bytes(const WgradGeom& g);
 int wgrad_slide_launch(const void* x, const void* dy, float* dw, void* ws, const WgradGeom& g, hipStream_t st);
+size_t wgrad_slide_pair_ws_bytes(const WgradGeom& g);
+int wgrad_slide_pair_launch(const void* x, const void* dy, const void* dy2, int lddy2, float* dw, float* dw2, void* ws,
+                            const WgradGeom& g, hipStream_t st);
 
 // wgrad_s2.hip (3x3x3 stride-2 / ConvTranspose weight gradient on the large levels: one parity-split input tile)
 bool wgrad_s2_eligible(const WgradGeom& g);

@@ -29,6 +29,9 @@
     X(ru3d_conv3d_wgrad) \
     X(ru3d_conv3d_wgrad_bias_workspace_bytes) \
     X(ru3d_conv3d_wgrad_bias) \
+    X(ru3d_conv3d_wgrad_pair_supported) \
+    X(ru3d_conv3d_wgrad_pair_workspace_bytes) \
+    X(ru3d_conv3d_wgrad_pair) \
     X(ru3d_head_bwd_supported) \
     X(ru3d_head_bwd_workspace_bytes) \
     X(ru3d_head_bwd) \
@@ -80,6 +83,9 @@
 #define ru3d_conv3d_wgrad ru3d_conv3d_wgrad_f16
 #define ru3d_conv3d_wgrad_bias_workspace_bytes ru3d_conv3d_wgrad_bias_workspace_bytes_f16
 #define ru3d_conv3d_wgrad_bias ru3d_conv3d_wgrad_bias_f16
+#define ru3d_conv3d_wgrad_pair_supported ru3d_conv3d_wgrad_pair_supported_f16
+#define ru3d_conv3d_wgrad_pair_workspace_bytes ru3d_conv3d_wgrad_pair_workspace_bytes_f16
+#define ru3d_conv3d_wgrad_pair ru3d_conv3d_wgrad_pair_f16
 #define ru3d_head_bwd_supported ru3d_head_bwd_supported_f16
 #define ru3d_head_bwd_workspace_bytes ru3d_head_bwd_workspace_bytes_f16
 #define ru3d_head_bwd ru3d_head_bwd_f16

@@ -25,7 +25,7 @@ constexpr int XPLANE = PROWS * 32;    // bf16 elements (64-byte rows, no pad: co
 constexpr int DPLANE = TH * TW * 32;  // DY plane: 256 rows
 constexpr int NSX = 6;                // X pieces (16 B) staged per thread and plane: 1360 / 256
 constexpr int NSD = 4;                // DY pieces per thread and plane: 1024 / 256
-static_assert((4 * XPLANE + 2 * DPLANE) * 2 <= 160 * 1024, "LDS budget");
+static_assert((4 * XPLANE + 4 * DPLANE) * 2 <= 160 * 1024, "LDS budget (PAIR: a second pair of DY planes)");
 
 struct WSlideArgs {
     const bf16* x;
@@ -37,6 +37,11 @@ struct WSlideArgs {
     int64_t x_segstride;
     int tiles_h, tiles_w, dsplit, DL, units;   // units per (ci, co) pair
     int light_last;                            // EDGE: the last column's far W half lies outside the volume
+    // PAIR: the weight gradient of a 1x1x1 conv of the SAME x (the decoder block's skip_conv, network.py:403-409) with its
+    // own gradient dy2, in the one tap slot of the four waves' 28 that no tap of the 3x3x3 conv fills
+    const bf16* dy2;
+    int lddy2;
+    float* part2;                              // [slab][ci][co]
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -59,12 +64,19 @@ __device__ __forceinline__ void static_for(F&& f) {
 // EDGE: W is not a multiple of 32.  The dy positions beyond W read zeros (dvoff); a column whose far W half lies outside
 // altogether skips the MFMAs of the odd k-steps (columns 16..31 of every row) - its staging runs as always - and such
 // light columns are dealt last, so that a launch with between one and two units per workgroup ends on them.
-template <bool EDGE>
+// PAIR: wave 3's seventh slot (tap 27 does not exist; the plain kernel recomputes tap 26 there and drops it) multiplies the
+// CENTRE tap's X fragment with the fragment of a second gradient tensor: dW2[ci][co] = sum_pos X[pos][ci] * DY2[pos][co],
+// the 1x1x1 skip conv's weight gradient, from the X planes that are in LDS anyway.  Costs a second pair of DY plane
+// buffers, four more staged pieces per thread and step, and one more fragment read per k-step in wave 3; saves the
+// separate pass over x (64 channels at 128^3: 124 us).
+template <bool EDGE, bool PAIR>
 __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16 lds[4 * XPLANE + 2 * DPLANE];
+    __shared__ __attribute__((aligned(16))) bf16 lds[4 * XPLANE + (PAIR ? 4 : 2) * DPLANE];
     bf16* const dbuf = lds + 4 * XPLANE;
+    bf16* const d2buf = lds + 4 * XPLANE + 2 * DPLANE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool pair_wave = PAIR && wave == 3;
     const int COT = a.Cout / 32;
     const int cit = blockIdx.y / COT, cot = blockIdx.y % COT;
 
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
     for (int t = 0; t < 7; t++) {
         // tap 27 (wave 3's 7th) does not exist: it recomputes tap 26 and is dropped at the end - the MFMA loop
         // stays free of branches
-        const int tap = wave + 4 * t < 27 ? wave + 4 * t : 26;
+        const int tap = wave + 4 * t < 27 ? wave + 4 * t : (PAIR ? 13 : 26);
         toff[t] = (((tap / 3) % 3) * WW + tap % 3) * 32;
     }
     f32x16 acc[7];
@@ -120,7 +132,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
         const int d0 = (t % a.dsplit) * a.DL;
         const int n = t / a.dsplit;
 
-        int xvoff[NSX], dvoff[NSD];
+        int xvoff[NSX], dvoff[NSD], d2voff[NSD];
 #pragma unroll
         for (int i = 0; i < NSX; i++) {
             const int r = (tid >> 2) + 64 * i, zh = r / WW, zw = r - zh * WW;
@@ -135,11 +147,16 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
             // contribution), as the X halo does
             dvoff[i] = (w0 + f % TW < a.W) ? (((h0 + f / TW) * a.W + w0 + f % TW) * a.lddy + cot * 32 + (tid & 3) * 8) * 2
                                            : (int)0x80000000;
+            d2voff[i] = (PAIR && w0 + f % TW < a.W)
+                            ? (((h0 + f / TW) * a.W + w0 + f % TW) * a.lddy2 + cot * 32 + (tid & 3) * 8) * 2
+                            : (int)0x80000000;
         }
         const bf16* xs = xbase + (int64_t)n * a.D * (xplane_b / 2);
         const bf16* ds = a.dy + (int64_t)n * a.D * (dplane_b / 2);
+        const int d2plane_b = PAIR ? a.H * a.W * a.lddy2 * 2 : 0, d2sample_b = a.D * d2plane_b;
+        const bf16* ds2 = PAIR ? a.dy2 + (int64_t)n * a.D * (d2plane_b / 2) : nullptr;
 
-        bf16x8 sx[NSX], sd[NSD];
+        bf16x8 sx[NSX], sd[NSD], sd2[NSD];
         auto load_x1 = [&](int pr, auto ic) {      // piece i of X plane d0 - 1 + pr
             constexpr int i = decltype(ic)::value;
             const int d = d0 - 1 + pr;
@@ -164,6 +181,17 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
             constexpr int i = decltype(ic)::value;
             *reinterpret_cast<bf16x8*>(sdst + 4 * XPLANE + buf * DPLANE + i * 64 * 32) = sd[i];
         };
+        auto load_d2_1 = [&](int s, auto ic) {      // piece i of DY2 plane d0 + s
+            constexpr int i = decltype(ic)::value;
+            const int d = d0 + s;
+            const bool dok = d < a.D;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ds2, (short)0, dok ? d2sample_b : 0, 0x00020000);
+            sd2[i] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, d2voff[i], dok ? d * d2plane_b : 0, 0));
+        };
+        auto store_d2_1 = [&](int buf, auto ic) {
+            constexpr int i = decltype(ic)::value;
+            *reinterpret_cast<bf16x8*>(sdst + 4 * XPLANE + (2 + buf) * DPLANE + i * 64 * 32) = sd2[i];
+        };
         auto load_x = [&](int pr) { static_for<0, NSX>([&](auto ic) { load_x1(pr, ic); }); };
         auto store_x = [&](int slot) { static_for<0, NSX>([&](auto ic) { store_x1(slot, ic); }); };
         auto load_d = [&](int s) { static_for<0, NSD>([&](auto ic) { load_d1(s, ic); }); };
@@ -174,24 +202,31 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
         load_x(1); store_x(1);
         load_x(2); store_x(2);
         load_d(0); store_d(0);
+        if constexpr (PAIR) {
+            static_for<0, NSD>([&](auto ic) { load_d2_1(0, ic); });
+            static_for<0, NSD>([&](auto ic) { store_d2_1(0, ic); });
+        }
         load_x(3);
         load_d(1);
+        if constexpr (PAIR) static_for<0, NSD>([&](auto ic) { load_d2_1(1, ic); });
         __syncthreads();
 
         auto step = [&](auto phc, int s) {
             constexpr int PH = decltype(phc)::value;
             const bf16* db = dbuf + (PH & 1) * DPLANE;
+            const bf16* d2b = d2buf + (PH & 1) * DPLANE;
             // fragments of k-step ks + 1 are fetched before the MFMAs of k-step ks (one wave per SIMD: nothing else
             // hides the LDS latency)
-            bf16x8 bq[3], aq[3][7];
+            bf16x8 bq[3], bq2[3], aq[3][7];
             auto fetch = [&](auto ksc, int buf) {
                 constexpr int ks = decltype(ksc)::value;
                 // positions f0 = 16 ks + 8 h: row ks >> 1 of the 8 x 32 plane tile, columns 16 (ks & 1) + 8 h ..
                 constexpr int rowb = (ks >> 1) * WW + (ks & 1) * 16;
                 bq[buf] = tr_frag(db + (ks * 16 + 8 * h) * 32 + lane_off);
+                if (pair_wave) bq2[buf] = tr_frag(d2b + (ks * 16 + 8 * h) * 32 + lane_off);
 #pragma unroll
                 for (int t = 0; t < 7; t++) {
-                    const int tap = wave + 4 * t < 27 ? wave + 4 * t : 26;
+                    const int tap = wave + 4 * t < 27 ? wave + 4 * t : (PAIR ? 13 : 26);
                     const int slot = (PH + tap / 9) & 3;
                     aq[buf][t] = tr_frag(lds + slot * XPLANE + (rowb + 8 * h) * 32 + toff[t] + lane_off);
                 }
@@ -205,16 +240,21 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
                 constexpr int rowb2 = (((ks + 2) & 15) >> 1) * WW + (((ks + 2) & 15) & 1) * 16;
                 static_for<0, 7>([&](auto tc) {
                     constexpr int t = decltype(tc)::value;
+                    // the pair slot takes the second gradient's fragment (a wave-uniform choice)
+                    const bf16x8 bsel = (PAIR && t == 6 && pair_wave) ? bq2[ks % 3] : bq[ks % 3];
                     if constexpr (EDGE && (ks & 1)) {
-                        if (!skip_far) acc[t] = RU3D_MFMA_32X32X16(aq[ks % 3][t], bq[ks % 3], acc[t], 0, 0, 0);
+                        if (!skip_far) acc[t] = RU3D_MFMA_32X32X16(aq[ks % 3][t], bsel, acc[t], 0, 0, 0);
                     } else {
-                        acc[t] = RU3D_MFMA_32X32X16(aq[ks % 3][t], bq[ks % 3], acc[t], 0, 0, 0);
+                        acc[t] = RU3D_MFMA_32X32X16(aq[ks % 3][t], bsel, acc[t], 0, 0, 0);
                     }
                     if constexpr (ks + 2 < 16) {
                         // (EDGE: the fragments of a k-step that issues no MFMAs are not fetched either)
                         if (!(EDGE && ((ks + 2) & 1)) || !skip_far) {
                             if constexpr (t == 0) bq[(ks + 2) % 3] = tr_frag(db + ((ks + 2) * 16 + 8 * h) * 32 + lane_off);
-                            const int tap = wave + 4 * t < 27 ? wave + 4 * t : 26;
+                            if constexpr (PAIR && t == 1) {
+                                if (pair_wave) bq2[(ks + 2) % 3] = tr_frag(d2b + ((ks + 2) * 16 + 8 * h) * 32 + lane_off);
+                            }
+                            const int tap = wave + 4 * t < 27 ? wave + 4 * t : (PAIR ? 13 : 26);
                             const int slot = (PH + tap / 9) & 3;
                             aq[(ks + 2) % 3][t] = tr_frag(lds + slot * XPLANE + (rowb2 + 8 * h) * 32 + toff[t] + lane_off);
                         }
@@ -231,6 +271,9 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
                 } else if constexpr (ks < NSX + NSD) {
                     store_d1((PH + 1) & 1, std::integral_constant<int, (ks >= NSX && ks < NSX + NSD ? ks - NSX : 0)>{});
                     load_d1(s + 2, std::integral_constant<int, (ks >= NSX && ks < NSX + NSD ? ks - NSX : 0)>{});
+                } else if constexpr (PAIR && ks < NSX + 2 * NSD) {
+                    store_d2_1((PH + 1) & 1, std::integral_constant<int, (ks >= NSX + NSD && ks < NSX + 2 * NSD ? ks - NSX - NSD : 0)>{});
+                    load_d2_1(s + 2, std::integral_constant<int, (ks >= NSX + NSD && ks < NSX + 2 * NSD ? ks - NSX - NSD : 0)>{});
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -246,6 +289,15 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s1_slide_kernel(WSlideArgs a) {
         }
     }
     // partial slab: part[((slab * 27 + tap) * Cin + ci) * Cout + co]; D row = ci, col = co
+    if (PAIR && pair_wave) {      // the skip conv's slab: [slab][ci][co]
+        float* pp = a.part2 + (int64_t)blockIdx.x * a.Cin * a.Cout;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int ci = cit * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+            const int co = cot * 32 + (lane & 31);
+            pp[(int64_t)ci * a.Cout + co] = acc[6][i];
+        }
+    }
 #pragma unroll
     for (int t = 0; t < 7; t++) {
         const int tap = wave + 4 * t;
@@ -314,7 +366,20 @@ size_t wgrad_slide_ws_bytes(const WgradGeom& g) {
     return (size_t)p.G * 27 * g.Cin * g.Cout * sizeof(float);
 }
 
+// the pair form's slabs: 27 + 1 taps
+size_t wgrad_slide_pair_ws_bytes(const WgradGeom& g) {
+    WgradSlidePlan p;
+    if (!wgrad_slide_plan(g, &p)) return 0;
+    return (size_t)p.G * 28 * g.Cin * g.Cout * sizeof(float);
+}
+
 int wgrad_slide_launch(const void* x, const void* dy, float* dw, void* ws, const WgradGeom& g, hipStream_t st) {
+    return wgrad_slide_pair_launch(x, dy, nullptr, 0, dw, nullptr, ws, g, st);
+}
+
+// dy2 != nullptr: also dw2[co][ci] = sum_pos x[pos][ci] * dy2[pos][co] (a 1x1x1 conv of the same x), PAIR kernel
+int wgrad_slide_pair_launch(const void* x, const void* dy, const void* dy2, int lddy2, float* dw, float* dw2, void* ws,
+                            const WgradGeom& g, hipStream_t st) {
     WgradSlidePlan p;
     if (!wgrad_slide_plan(g, &p)) return ru3d_fail(-1, "wgrad_slide: shape not supported");
     WSlideArgs a;
@@ -327,11 +392,22 @@ int wgrad_slide_launch(const void* x, const void* dy, float* dw, void* ws, const
     if (g.x_cseg && (g.x_cseg % 32)) return ru3d_fail(-1, "wgrad_slide: split x needs segments of whole 32-channel tiles");
     a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w; a.dsplit = p.dsplit; a.DL = p.DL; a.units = p.units;
     a.light_last = (g.Wo % TW) != 0 && (g.Wo % TW) <= 16 && p.tiles_w > 1;
-    if (g.Wo % TW) hipLaunchKernelGGL(wgrad3_s1_slide_kernel<true>, dim3(p.G, p.pairs), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(wgrad3_s1_slide_kernel<false>, dim3(p.G, p.pairs), dim3(256), 0, st, a);
+    a.dy2 = (const bf16*)dy2;
+    a.lddy2 = lddy2;
+    a.part2 = (float*)ws + (size_t)p.G * 27 * g.Cin * g.Cout;
+    if (dy2) {
+        if (g.Wo % TW) hipLaunchKernelGGL((wgrad3_s1_slide_kernel<true, true>), dim3(p.G, p.pairs), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wgrad3_s1_slide_kernel<false, true>), dim3(p.G, p.pairs), dim3(256), 0, st, a);
+    } else {
+        if (g.Wo % TW) hipLaunchKernelGGL((wgrad3_s1_slide_kernel<true, false>), dim3(p.G, p.pairs), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((wgrad3_s1_slide_kernel<false, false>), dim3(p.G, p.pairs), dim3(256), 0, st, a);
+    }
     int rc = ru3d_check_launch("wgrad3_s1_slide");
     if (rc) return rc;
-    return wgrad_reduce_launch((const float*)ws, dw, p.G, 27, g.Cin, g.Cout, g.s_o, g.s_i, st);
+    rc = wgrad_reduce_launch((const float*)ws, dw, p.G, 27, g.Cin, g.Cout, g.s_o, g.s_i, st);
+    if (rc || !dy2) return rc;
+    // the 1x1x1 weight in the reference layout [Cout][Cin]
+    return wgrad_reduce_launch(a.part2, dw2, p.G, 1, g.Cin, g.Cout, (int64_t)g.Cin, 1, st);
 }
 
 }  // namespace RU3D_NS

@@ -188,3 +188,37 @@ def test_conv3_s1_32to32_full_size_random_data():
     ref_w = torch.nn.grad.conv3d_weight(xr, wr.shape, gyr, padding=1)
     # fp32 accumulation over 4.2 M positions: relative to the gradient's max, not to one rounding
     _close(gw, ref_w, 2e-3, 1e-3, "32->32 wgrad 2x128^3")
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("cin,cout,n,dims,split", [(64, 32, 2, (64, 64, 64), False), (64, 32, 2, (64, 64, 64), True),
+                                                   (128, 64, 2, (32, 32, 64), False), (64, 32, 2, (32, 64, 40), False),
+                                                   (64, 32, 1, (64, 64, 96), True), (32, 32, 3, (64, 64, 32), False)])
+def test_wgrad_pair(dt, cin, cout, n, dims, split):
+    """Decoder ResBlock backward (network.py:403-409 read backwards): the weight gradients of conv1 (3x3x3) and skip_conv
+    (1x1x1) on the same input from one pass over it (ru3d_conv3d_wgrad_pair: the sliding kernel's free tap slot), x dense
+    or as the two planes of the level-0 concat, W a multiple of 32 or not.  The 3x3x3 part is bit for bit what the plain
+    entry point returns (same kernel, same order); the 1x1x1 part is held against torch-CPU on storage-rounded operands."""
+    g = torch.Generator().manual_seed(cin + cout + n + sum(dims) + int(split))
+    d, h, w = dims
+    xv = torch.randn(n, cin, d, h, w, generator=g)
+    g1 = torch.randn(n, cout, d, h, w, generator=g)
+    g2 = torch.randn(n, cout, d, h, w, generator=g)
+    if split:       # [u | skip] as two planes of one buffer
+        buf = ops.as_input(torch.cat((xv[:, :cin // 2], xv[:, cin // 2:]), dim=0).to(DEV), dt)
+        x = N.Split(buf)
+    else:
+        x = ops.as_input(xv.to(DEV), dt)
+    dy1 = ops.as_input(g1.to(DEV), dt)
+    dy2 = ops.as_input(g2.to(DEV), dt)
+    both = ops.conv_wgrad_pair(x, dy1, dy2)
+    assert both is not None, "no fused kernel for %s" % (dims,)
+    gw3, gw1 = both
+    plain3 = ops.conv_wgrad(x, dy1, 3, 1)
+    assert torch.equal(gw3, plain3), "3x3x3 part differs from the plain sliding kernel"
+    ref1 = torch.nn.grad.conv3d_weight(_rt(xv, dt), (cout, cin, 1, 1, 1), _rt(g2, dt))
+    # fp32 accumulation over up to 200 k positions per sample: relative to the gradient's maximum
+    _close(gw1, ref1, 2e-3, 1e-3, "1x1x1 weight gradient from the pair kernel %s %s" % ((cin, cout), dims))
+    if not split:
+        plain1 = ops.conv_wgrad(x, dy2, 1, 1)
+        _close(gw1, plain1, 1e-4, 1e-4, "pair vs staged 1x1x1 weight gradient")
