@@ -76,9 +76,9 @@ SIGNATURES = {
     "ru3d_conv3d_wgrad": (_i, [_P, _P, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "ru3d_conv3d_wgrad_bias_workspace_bytes": (_sz, [_P, _P, _i, _i, _i]),
     "ru3d_conv3d_wgrad_bias": (_i, [_P, _P, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
-    "ru3d_conv3d_wgrad_pair_supported": (_i, [_P, _P, _P, _i]),
-    "ru3d_conv3d_wgrad_pair_workspace_bytes": (_sz, [_P, _P, _P, _i]),
-    "ru3d_conv3d_wgrad_pair": (_i, [_P, _P, _P, _vp, _vp, _vp, _sz, _i, _vp]),
+    "ru3d_conv3d_wgrad_pair_supported": (_i, [_P, _P, _P, _i, _i]),
+    "ru3d_conv3d_wgrad_pair_workspace_bytes": (_sz, [_P, _P, _P, _i, _i]),
+    "ru3d_conv3d_wgrad_pair": (_i, [_P, _P, _P, _vp, _vp, _vp, _sz, _i, _i, _vp]),
     "ru3d_head_bwd_supported": (_i, [_P, _P, _P, _i]),
     "ru3d_head_bwd_workspace_bytes": (_sz, [_P, _i]),
     "ru3d_head_bwd": (_i, [_P, _P, _vp, _i, _P, _vp, _vp, _vp, _sz, _i, _vp]),

@@ -373,30 +373,30 @@ def conv_wgrad(x, dy, k, stride, key=None):
     return dw
 
 
-def _wgrad_pair_ok(x, dy):
+def _wgrad_pair_ok(x, dy, stride=1):
     """ru3d_conv3d_wgrad_pair takes (x, dy, dy2) with dy2 shaped like dy: asked with dy in both places"""
     if x.dtype == torch.float32:
         return False
     dx, ddy = desc(x), desc(dy)
-    return bool(N.lib.ru3d_conv3d_wgrad_pair_supported(ref(dx), ref(ddy), ref(ddy), N.dtype_code(x.dtype)))
+    return bool(N.lib.ru3d_conv3d_wgrad_pair_supported(ref(dx), ref(ddy), ref(ddy), stride, N.dtype_code(x.dtype)))
 
 
-def conv_wgrad_pair(x, dy, dy2, key=None, key2=None):
-    """(dW of the 3x3x3 stride-1 conv on x with gradient dy, dW of a 1x1x1 conv on the same x with gradient dy2) from one
-    pass over x (ru3d_conv3d_wgrad_pair: the decoder ResBlock's conv1 + skip_conv), or None when the shapes have no fused
+def conv_wgrad_pair(x, dy, dy2, stride=1, key=None, key2=None):
+    """(dW of the 3x3x3 conv on x with gradient dy, dW of a 1x1x1 conv of the same stride on the same x with gradient dy2)
+    from one pass over x (ru3d_conv3d_wgrad_pair: a ResBlock's conv1 + skip_conv), or None when the shapes have no fused
     kernel."""
     if x.dtype == torch.float32 or tuple(dy.shape) != tuple(dy2.shape):
         return None
     dx, ddy, ddy2 = desc(x), desc(dy), desc(dy2)
     code = N.dtype_code(x.dtype)
-    if not N.lib.ru3d_conv3d_wgrad_pair_supported(ref(dx), ref(ddy), ref(ddy2), code):
+    if not N.lib.ru3d_conv3d_wgrad_pair_supported(ref(dx), ref(ddy), ref(ddy2), stride, code):
         return None
     cout, cin = dy.shape[1], x.shape[1]
     dw = _grad_out(key, (cout, cin, 3, 3, 3), x.device)
     dw2 = _grad_out(key2, (cout, cin, 1, 1, 1), x.device)
-    ws = N.workspace(N.lib.ru3d_conv3d_wgrad_pair_workspace_bytes(ref(dx), ref(ddy), ref(ddy2), code), x.device)
-    check(N.lib.ru3d_conv3d_wgrad_pair(ref(dx), ref(ddy), ref(ddy2), ptr(dw), ptr(dw2), ptr(ws), ws.numel(), code, stream()),
-          "conv3d_wgrad_pair")
+    ws = N.workspace(N.lib.ru3d_conv3d_wgrad_pair_workspace_bytes(ref(dx), ref(ddy), ref(ddy2), stride, code), x.device)
+    check(N.lib.ru3d_conv3d_wgrad_pair(ref(dx), ref(ddy), ref(ddy2), ptr(dw), ptr(dw2), ptr(ws), ws.numel(), stride, code,
+                                       stream()), "conv3d_wgrad_pair")
     return dw, dw2
 
 
@@ -1136,9 +1136,9 @@ class ResBlockFn(torch.autograd.Function):
         gws = gbs = None
         nvox = dy2.shape[0] * dy2.shape[2] * dy2.shape[3] * dy2.shape[4]
         xk = x.t if ctx.planar else x
-        # stride-1 block with a skip conv (decoder): its weight gradient rides in the free tap slot of conv1's sliding
-        # weight-gradient kernel further down - one pass over x instead of two
-        pair_later = ctx.has_skip_conv and stride == 1 and _wgrad_pair_ok(x, gpre)
+        # a block with a skip conv (decoder blocks: stride 1, pooling blocks: stride 2): its weight gradient rides in the
+        # free tap slot of conv1's weight-gradient kernel further down - one pass over x instead of two
+        pair_later = ctx.has_skip_conv and _wgrad_pair_ok(x, gpre, stride)
         with _OnSide(dev, nvox, (a1, dy2, xk, gpre)):
             gw2 = unpad_wgrad(conv_wgrad(a1, dy2, 3, 1, key=ctx.wkeys[1]), cout, cout, cout_seg, cout_seg)
             if ctx.has_skip_conv:
@@ -1151,7 +1151,7 @@ class ResBlockFn(torch.autograd.Function):
         dy1 = conv_dgrad_in_bwd(dy2, pw2d, a1, mean1, scale1)
         del dy2, a1, y1
         with _OnSide(dev, nvox, (xk, dy1, gpre)):
-            both = conv_wgrad_pair(x, dy1, gpre, key=ctx.wkeys[0], key2=ctx.wkeys[2]) if pair_later else None
+            both = conv_wgrad_pair(x, dy1, gpre, stride, key=ctx.wkeys[0], key2=ctx.wkeys[2]) if pair_later else None
             if both is not None:
                 gw1 = unpad_wgrad(both[0], cout, cin, cout_seg, cin_seg)
                 gws = unpad_wgrad(both[1], cout, cin, cout_seg, cin_seg)

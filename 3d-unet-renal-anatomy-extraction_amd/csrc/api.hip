@@ -650,42 +650,51 @@ extern "C" int ru3d_conv3d_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, fl
 }
 
 
-// ---- the decoder ResBlock's two weight gradients on its input x (conv1: 3x3x3, skip_conv: 1x1x1; network.py:403-409) from
-// ONE pass over x: the sliding weight-gradient kernel has one tap slot of its four waves' 28 free (wgrad_slide.hip, PAIR)
-static bool wgrad_pair_ok(const ru3d_tensor* x, const ru3d_tensor* dy, const ru3d_tensor* dy2, int dtype) {
+// ---- a ResBlock's two weight gradients on its input x (conv1: 3x3x3, skip_conv: 1x1x1, both with the block's stride;
+// network.py:403-409) from ONE pass over x: the sliding (stride 1: wgrad_slide.hip) and the LDS-DMA (stride 2: wgrad_s2.hip)
+// weight-gradient kernels have one tap slot of their four waves' 28 free, and the centre tap's rows are the rows the 1x1x1
+// conv reads
+static bool wgrad_pair_ok(const ru3d_tensor* x, const ru3d_tensor* dy, const ru3d_tensor* dy2, int stride, int dtype) {
     static const int mode = getenv("RU3D_WGRAD_PAIR") ? atoi(getenv("RU3D_WGRAD_PAIR")) : 1;      // 0 = two launches
-    if (!mode || dtype != RU3D_BF16) return false;
-    if (!wgrad_shapes_ok(x, dy, 3, 1) || !tensor_ok(dy2)) return false;
+    if (!mode || dtype != RU3D_BF16 || (stride != 1 && stride != 2)) return false;
+    if (!wgrad_shapes_ok(x, dy, 3, stride) || !tensor_ok(dy2)) return false;
     if (dy2->n != dy->n || dy2->d != dy->d || dy2->h != dy->h || dy2->w != dy->w || dy2->c != dy->c) return false;
     if ((dy2->ld % 8) || ((((uintptr_t)x->ptr) | ((uintptr_t)dy->ptr) | ((uintptr_t)dy2->ptr)) % 16)) return false;
     if ((int64_t)dy->d * dy->h * dy->w * dy2->ld >= (1ll << 30)) return false;
-    WgradGeom g = make_wgrad(x, dy, 3, 1);
+    WgradGeom g = make_wgrad(x, dy, 3, stride);
     if (g.x_cseg && (g.x_cseg % 32)) return false;
     if (!mfma_wgrad_eligible(g, dtype)) return false;
+    if (stride == 2) return wgrad_s2_pair_eligible(g);
     WgradSlidePlan sp;
     return wgrad_slide_plan(g, &sp);
 }
 
-extern "C" int ru3d_conv3d_wgrad_pair_supported(const ru3d_tensor* x, const ru3d_tensor* dy, const ru3d_tensor* dy2, int dtype) {
-    RU3D_FWD_F16(dtype, ru3d_conv3d_wgrad_pair_supported_f16(x, dy, dy2, dtype));
-    return (x && dy && dy2 && wgrad_pair_ok(x, dy, dy2, dtype)) ? 1 : 0;
+extern "C" int ru3d_conv3d_wgrad_pair_supported(const ru3d_tensor* x, const ru3d_tensor* dy, const ru3d_tensor* dy2, int stride,
+                                                int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_wgrad_pair_supported_f16(x, dy, dy2, stride, dtype));
+    return (x && dy && dy2 && wgrad_pair_ok(x, dy, dy2, stride, dtype)) ? 1 : 0;
 }
 
 extern "C" size_t ru3d_conv3d_wgrad_pair_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* dy, const ru3d_tensor* dy2,
-                                                         int dtype) {
-    RU3D_FWD_F16(dtype, ru3d_conv3d_wgrad_pair_workspace_bytes_f16(x, dy, dy2, dtype));
-    if (!x || !dy || !dy2 || !wgrad_pair_ok(x, dy, dy2, dtype)) return 0;
-    return wgrad_slide_pair_ws_bytes(make_wgrad(x, dy, 3, 1));
+                                                         int stride, int dtype) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_wgrad_pair_workspace_bytes_f16(x, dy, dy2, stride, dtype));
+    if (!x || !dy || !dy2 || !wgrad_pair_ok(x, dy, dy2, stride, dtype)) return 0;
+    const WgradGeom g = make_wgrad(x, dy, 3, stride);
+    return stride == 2 ? wgrad_s2_pair_ws_bytes(g) : wgrad_slide_pair_ws_bytes(g);
 }
 
 extern "C" int ru3d_conv3d_wgrad_pair(const ru3d_tensor* x, const ru3d_tensor* dy, const ru3d_tensor* dy2, float* dw,
-                                      float* dw2, void* ws, size_t ws_bytes, int dtype, void* stream) {
-    RU3D_FWD_F16(dtype, ru3d_conv3d_wgrad_pair_f16(x, dy, dy2, dw, dw2, ws, ws_bytes, dtype, stream));
+                                      float* dw2, void* ws, size_t ws_bytes, int stride, int dtype, void* stream) {
+    RU3D_FWD_F16(dtype, ru3d_conv3d_wgrad_pair_f16(x, dy, dy2, dw, dw2, ws, ws_bytes, stride, dtype, stream));
     Ru3dDeviceGuard dev_guard(stream);
-    RU3D_REQUIRE(x && dy && dy2 && wgrad_pair_ok(x, dy, dy2, dtype),
+    RU3D_REQUIRE(x && dy && dy2 && wgrad_pair_ok(x, dy, dy2, stride, dtype),
                  "conv3d_wgrad_pair: shapes have no fused kernel (ask ru3d_conv3d_wgrad_pair_supported first)");
     RU3D_REQUIRE(dw && dw2 && ws, "conv3d_wgrad_pair: null output / workspace");
-    WgradGeom g = make_wgrad(x, dy, 3, 1);
+    WgradGeom g = make_wgrad(x, dy, 3, stride);
+    if (stride == 2) {
+        RU3D_REQUIRE(ws_bytes >= wgrad_s2_pair_ws_bytes(g), "conv3d_wgrad_pair: workspace too small");
+        return wgrad_s2_pair_launch(x->ptr, dy->ptr, dy2->ptr, dy2->ld, dw, dw2, ws, g, as_stream(stream));
+    }
     RU3D_REQUIRE(ws_bytes >= wgrad_slide_pair_ws_bytes(g), "conv3d_wgrad_pair: workspace too small");
     return wgrad_slide_pair_launch(x->ptr, dy->ptr, dy2->ptr, dy2->ld, dw, dw2, ws, g, as_stream(stream));
 }

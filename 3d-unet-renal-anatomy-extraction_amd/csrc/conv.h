@@ -176,6 +176,10 @@ int wgrad_slide_pair_launch(const void* x, const void* dy, const void* dy2, int 
 bool wgrad_s2_eligible(const WgradGeom& g);
 size_t wgrad_s2_ws_bytes(const WgradGeom& g);
 int wgrad_s2_launch(const void* x, const void* dy, float* dw, void* ws, const WgradGeom& g, hipStream_t st);
+bool wgrad_s2_pair_eligible(const WgradGeom& g);
+size_t wgrad_s2_pair_ws_bytes(const WgradGeom& g);
+int wgrad_s2_pair_launch(const void* x, const void* dy, const void* dy2, int lddy2, float* dw, float* dw2, void* ws,
+                         const WgradGeom& g, hipStream_t st);
 
 // small_convs.hip (1-channel stem, 2..4-channel head)
 bool stem_fwd_eligible(const ConvGeom& g, int dtype, int y_dtype, const void* res);

@@ -29,6 +29,11 @@ struct WS2Args {
     int N, Di, Hi, Wi, Do, Ho, Wo;
     int Cin, Cout, ldx, lddy;
     int tiles_d, tiles_h, tiles_w, ntiles, G;
+    // PAIR (DMA kernel): the 1x1x1 stride-2 skip conv's weight gradient (same x, its own gradient dy2 shaped like dy) in
+    // the tap slot no tap of the 3x3x3 conv fills - the centre tap's gathered rows ARE the rows that conv reads
+    const bf16* dy2;
+    int lddy2;
+    float* part2;      // [slab][ci][co]
 };
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
@@ -183,20 +188,23 @@ constexpr int DNPOS = TDO * THO * DW;                   // 64 positions
 constexpr int DXINSTR = (DXROWS * 4 + 63) / 64;         // 52 wave-instructions fill the input tile
 constexpr int DXI = (DXINSTR + 3) / 4;                  // 13 per wave
 constexpr int DXBUF = DXINSTR * 64 * 8;                 // elements per input buffer (53,248 B incl. the tail slots)
-static_assert(2 * (DXBUF + 2 * DNPOS * 32) * 2 <= 160 * 1024, "LDS budget");
+static_assert(2 * (DXBUF + 4 * DNPOS * 32) * 2 <= 160 * 1024, "LDS budget (PAIR: the second gradient's rows)");
 
-template <int NCO>
+template <int NCO, bool PAIR>
 __global__ __launch_bounds__(256, 1) void wgrad3_s2_dma_kernel(WS2Args a) {
-    __shared__ __attribute__((aligned(16))) bf16 lds[2 * (DXBUF + NCO * DNPOS * 32)];
+    constexpr int NDY = PAIR ? 2 * NCO : NCO;          // DY tiles per buffer: dy's, then dy2's
+    constexpr int BUFE = DXBUF + NDY * DNPOS * 32;
+    __shared__ __attribute__((aligned(16))) bf16 lds[2 * BUFE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int COT = a.Cout / (32 * NCO);
     const int cit = blockIdx.y / COT, cot = (blockIdx.y % COT) * NCO;
+    const bool pair_wave = PAIR && wave == 3;
 
     int toff[7];
 #pragma unroll
     for (int t = 0; t < 7; t++) {
-        const int tap = wave + 4 * t < 27 ? wave + 4 * t : 26;
+        const int tap = wave + 4 * t < 27 ? wave + 4 * t : (PAIR ? 13 : 26);
         const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
         toff[t] = ((kd * LH + kh) * DLW + (kw == 1 ? DNE : (kw >> 1))) * 32;
     }
@@ -225,6 +233,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s2_dma_kernel(WS2Args a) {
         zz[i] = slot_ok ? (dz | (dh << 8) | (e << 16)) : -1;
     }
     const int xsample_b = a.Di * a.Hi * a.Wi * a.ldx * 2, dsample_b = a.Do * a.Ho * a.Wo * a.lddy * 2;
+    const int d2sample_b = PAIR ? a.Do * a.Ho * a.Wo * a.lddy2 * 2 : 0;
 
     auto issue_tile = [&](int tile, int buf) {
         int tt = tile;
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s2_dma_kernel(WS2Args a) {
         const bool interior = id0 >= 0 && id0 + LD <= a.Di && ih0 >= 0 && ih0 + LH <= a.Hi && iw0 >= 0 && iw0 + DLW <= a.Wi;
         const int org = (((id0 * a.Hi + ih0) * a.Wi + iw0) * a.ldx + cit * 32) * 2;   // may be negative on a border tile
         const ru3d_i32x4 rx = ru3d_buffer_rsrc(a.x + (int64_t)n * (xsample_b / 2), xsample_b);
-        bf16* xb = lds + buf * (DXBUF + NCO * DNPOS * 32);
+        bf16* xb = lds + buf * BUFE;
 #pragma unroll
         for (int i = 0; i < DXI; i++) {
             if (wave + 4 * i < DXINSTR) {                                            // wave-uniform
@@ -259,6 +268,13 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s2_dma_kernel(WS2Args a) {
 #pragma unroll
         for (int o = 0; o < NCO; o++)
             ru3d_lds_dma16(rd, db + o * (DNPOS * 32) + wave * 512, doff + o * 64);
+        if constexpr (PAIR) {
+            const ru3d_i32x4 rd2 = ru3d_buffer_rsrc(a.dy2 + (int64_t)n * (d2sample_b / 2), d2sample_b);
+            const int d2off = (((od * a.Ho + oh) * a.Wo + ow) * a.lddy2 + cot * 32 + (lane & 3) * 8) * 2;
+#pragma unroll
+            for (int o = 0; o < NCO; o++)
+                ru3d_lds_dma16(rd2, db + (NCO + o) * (DNPOS * 32) + wave * 512, d2off + o * 64);
+        }
     };
 
     if ((int)blockIdx.x < a.ntiles) issue_tile(blockIdx.x, 0);
@@ -266,24 +282,42 @@ __global__ __launch_bounds__(256, 1) void wgrad3_s2_dma_kernel(WS2Args a) {
     for (int tile = blockIdx.x; tile < a.ntiles; tile += a.G, buf ^= 1) {
         ru3d_dma_landed_barrier();   // this tile's rows have landed, the other buffer is free
         if (tile + a.G < a.ntiles) issue_tile(tile + a.G, buf ^ 1);
-        const bf16* xs = lds + buf * (DXBUF + NCO * DNPOS * 32);
+        const bf16* xs = lds + buf * BUFE;
         const bf16* ds = xs + DXBUF;
 #pragma unroll
         for (int ks = 0; ks < DNPOS / 16; ks++) {
             // positions 16 ks + 8 h ..: output (ks >> 1, ks & 1, 8 h ..): gathered line (2 od, 2 oh), even entries 8 h ..
             const int rowb = ((2 * (ks >> 1)) * LH + 2 * (ks & 1)) * DLW + 8 * h;
-            bf16x8 bfrag[NCO];
+            bf16x8 bfrag[NCO], bfrag2[NCO];
 #pragma unroll
             for (int o = 0; o < NCO; o++) bfrag[o] = tr_frag(ds + o * (DNPOS * 32) + (ks * 16 + 8 * h) * 32 + lane_off);
+            if (pair_wave) {
+#pragma unroll
+                for (int o = 0; o < NCO; o++)
+                    bfrag2[o] = tr_frag(ds + (NCO + o) * (DNPOS * 32) + (ks * 16 + 8 * h) * 32 + lane_off);
+            }
 #pragma unroll
             for (int t = 0; t < 7; t++) {
                 const bf16x8 afrag = tr_frag(xs + rowb * 32 + toff[t] + lane_off);
 #pragma unroll
-                for (int o = 0; o < NCO; o++)
-                    acc[t][o] = RU3D_MFMA_32X32X16(afrag, bfrag[o], acc[t][o], 0, 0, 0);
+                for (int o = 0; o < NCO; o++) {
+                    const bf16x8 bsel = (PAIR && t == 6 && pair_wave) ? bfrag2[o] : bfrag[o];
+                    acc[t][o] = RU3D_MFMA_32X32X16(afrag, bsel, acc[t][o], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+    if (PAIR && pair_wave) {
+        float* pp = a.part2 + (int64_t)blockIdx.x * a.Cin * a.Cout;
+#pragma unroll
+        for (int o = 0; o < NCO; o++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int ci = cit * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                const int co = (cot + o) * 32 + (lane & 31);
+                pp[(int64_t)ci * a.Cout + co] = acc[6][o][i];
+            }
     }
 #pragma unroll
     for (int t = 0; t < 7; t++) {
@@ -337,8 +371,23 @@ size_t wgrad_s2_ws_bytes(const WgradGeom& g) {
     return (size_t)s2_groups(g, ntiles) * 27 * g.Cin * g.Cout * sizeof(float);
 }
 
+bool wgrad_s2_pair_eligible(const WgradGeom& g) { return wgrad_s2_eligible(g) && s2_dma(g) && !g.x_cseg; }
+
+size_t wgrad_s2_pair_ws_bytes(const WgradGeom& g) {
+    if (!wgrad_s2_pair_eligible(g)) return 0;
+    const int64_t ntiles = (int64_t)g.N * (g.Do / TDO) * (g.Ho / THO) * (g.Wo / s2_tw(g));
+    return (size_t)s2_groups(g, ntiles) * 28 * g.Cin * g.Cout * sizeof(float);
+}
+
 int wgrad_s2_launch(const void* x, const void* dy, float* dw, void* ws, const WgradGeom& g, hipStream_t st) {
+    return wgrad_s2_pair_launch(x, dy, nullptr, 0, dw, nullptr, ws, g, st);
+}
+
+// dy2 != nullptr: also dw2[co][ci] = sum_pos x[2 pos][ci] * dy2[pos][co] (the 1x1x1 stride-2 conv of the same x)
+int wgrad_s2_pair_launch(const void* x, const void* dy, const void* dy2, int lddy2, float* dw, float* dw2, void* ws,
+                         const WgradGeom& g, hipStream_t st) {
     if (!wgrad_s2_eligible(g)) return ru3d_fail(-1, "wgrad_s2: shape not supported");
+    if (dy2 && !wgrad_s2_pair_eligible(g)) return ru3d_fail(-1, "wgrad_s2: no pair form for this shape");
     const int tw = s2_tw(g), nco = s2_nco(g);
     WS2Args a;
     a.x = (const bf16*)x;
@@ -349,17 +398,27 @@ int wgrad_s2_launch(const void* x, const void* dy, float* dw, void* ws, const Wg
     a.tiles_d = g.Do / TDO; a.tiles_h = g.Ho / THO; a.tiles_w = g.Wo / tw;
     a.ntiles = g.N * a.tiles_d * a.tiles_h * a.tiles_w;
     a.G = s2_groups(g, a.ntiles);
+    a.dy2 = (const bf16*)dy2;
+    a.lddy2 = lddy2;
+    a.part2 = (float*)ws + (size_t)a.G * 27 * g.Cin * g.Cout;
     const dim3 grid(a.G, (g.Cin / 32) * (g.Cout / (32 * nco)));
     if (s2_dma(g)) {
-        if ((((uintptr_t)x) | ((uintptr_t)dy)) % 16) return ru3d_fail(-1, "wgrad_s2: x / dy must be 16-byte aligned");
-        if (nco == 2) hipLaunchKernelGGL(wgrad3_s2_dma_kernel<2>, grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(wgrad3_s2_dma_kernel<1>, grid, dim3(256), 0, st, a);
+        if ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dy2)) % 16) return ru3d_fail(-1, "wgrad_s2: x / dy must be 16-byte aligned");
+        if (dy2) {
+            if (nco == 2) hipLaunchKernelGGL((wgrad3_s2_dma_kernel<2, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((wgrad3_s2_dma_kernel<1, true>), grid, dim3(256), 0, st, a);
+        } else {
+            if (nco == 2) hipLaunchKernelGGL((wgrad3_s2_dma_kernel<2, false>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((wgrad3_s2_dma_kernel<1, false>), grid, dim3(256), 0, st, a);
+        }
     } else {
         hipLaunchKernelGGL(wgrad3_s2_tile_kernel<1>, grid, dim3(256), 0, st, a);
     }
     int rc = ru3d_check_launch("wgrad3_s2_tile");
     if (rc) return rc;
-    return wgrad_reduce_launch((const float*)ws, dw, a.G, 27, g.Cin, g.Cout, g.s_o, g.s_i, st);
+    rc = wgrad_reduce_launch((const float*)ws, dw, a.G, 27, g.Cin, g.Cout, g.s_o, g.s_i, st);
+    if (rc || !dy2) return rc;
+    return wgrad_reduce_launch(a.part2, dw2, a.G, 1, g.Cin, g.Cout, (int64_t)g.Cin, 1, st);
 }
 
 }  // namespace RU3D_NS

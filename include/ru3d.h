@@ -176,14 +176,15 @@ size_t ru3d_conv3d_wgrad_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor
 int ru3d_conv3d_wgrad(const ru3d_tensor* x, const ru3d_tensor* dy, float* dw, void* ws, size_t ws_bytes,
                       int k, int stride, int dtype, void* stream);
 
-/* The decoder ResBlock's two weight gradients on its input x (reference network.py:403-409: conv1 3x3x3 stride 1 and
- * skip_conv 1x1x1 on the same x) from ONE pass over x:  dw[Cout][Cin][27] = wgrad3(x, dy),  dw2[Cout][Cin] = wgrad1(x, dy2).
- * dy and dy2 have the same shape.  x may be a split tensor.  Ask _supported first (the sliding weight-gradient kernel's
- * shapes, 16-bit storage); workspace: _workspace_bytes. */
-int ru3d_conv3d_wgrad_pair_supported(const ru3d_tensor* x, const ru3d_tensor* dy, const ru3d_tensor* dy2, int dtype);
-size_t ru3d_conv3d_wgrad_pair_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* dy, const ru3d_tensor* dy2, int dtype);
+/* A ResBlock's two weight gradients on its input x (reference network.py:403-409: conv1 3x3x3 and skip_conv 1x1x1, both
+ * with the block's stride 1 or 2, on the same x) from ONE pass over x:  dw[Cout][Cin][27] = wgrad3(x, dy),
+ * dw2[Cout][Cin] = wgrad1(x, dy2).  dy and dy2 have the same shape.  x may be a split tensor (stride 1).  Ask _supported
+ * first (the sliding / LDS-DMA weight-gradient kernels' shapes, 16-bit storage); workspace: _workspace_bytes. */
+int ru3d_conv3d_wgrad_pair_supported(const ru3d_tensor* x, const ru3d_tensor* dy, const ru3d_tensor* dy2, int stride, int dtype);
+size_t ru3d_conv3d_wgrad_pair_workspace_bytes(const ru3d_tensor* x, const ru3d_tensor* dy, const ru3d_tensor* dy2, int stride,
+                                              int dtype);
 int ru3d_conv3d_wgrad_pair(const ru3d_tensor* x, const ru3d_tensor* dy, const ru3d_tensor* dy2, float* dw, float* dw2,
-                           void* ws, size_t ws_bytes, int dtype, void* stream);
+                           void* ws, size_t ws_bytes, int stride, int dtype, void* stream);
 /* The same weight gradient AND the conv's bias gradient db[co] = sum over samples and voxels of dy (autograd of the bias of
  * network.py:541 conv / any nn.Conv3d) behind one entry point: the stem's MFMA kernel delivers db from its own pass over dy
  * (an extra all-ones row of its im2col operand); other shapes run ru3d_conv3d_wgrad + ru3d_channel_sum. */

@@ -211,7 +211,7 @@ def test_wgrad_pair(dt, cin, cout, n, dims, split):
         x = ops.as_input(xv.to(DEV), dt)
     dy1 = ops.as_input(g1.to(DEV), dt)
     dy2 = ops.as_input(g2.to(DEV), dt)
-    both = ops.conv_wgrad_pair(x, dy1, dy2)
+    both = ops.conv_wgrad_pair(x, dy1, dy2, 1)
     assert both is not None, "no fused kernel for %s" % (dims,)
     gw3, gw1 = both
     plain3 = ops.conv_wgrad(x, dy1, 3, 1)
@@ -222,3 +222,27 @@ def test_wgrad_pair(dt, cin, cout, n, dims, split):
     if not split:
         plain1 = ops.conv_wgrad(x, dy2, 1, 1)
         _close(gw1, plain1, 1e-4, 1e-4, "pair vs staged 1x1x1 weight gradient")
+
+
+@pytest.mark.parametrize("dt", DTYPES, ids=["bf16", "fp16"])
+@pytest.mark.parametrize("cin,cout,n,dims", [(32, 64, 2, (64, 64, 64)), (64, 128, 2, (32, 64, 64)), (32, 64, 3, (32, 32, 96)),
+                                             (128, 256, 2, (32, 32, 32)), (32, 32, 2, (64, 32, 64))])
+def test_wgrad_pair_stride2(dt, cin, cout, n, dims):
+    """Pooling ResBlock backward: the weight gradients of conv1 (3x3x3 stride 2) and skip_conv (1x1x1 stride 2) on the same
+    input from one pass (the LDS-DMA stride-2 kernel's free tap slot: its centre tap gathers x[2 o], the rows the 1x1x1
+    conv reads).  3x3x3 part bit for bit the plain kernel's, 1x1x1 part against torch-CPU."""
+    g = torch.Generator().manual_seed(cin + cout + n + sum(dims))
+    d, h, w = dims
+    xv = torch.randn(n, cin, d, h, w, generator=g)
+    g1 = torch.randn(n, cout, d // 2, h // 2, w // 2, generator=g)
+    g2 = torch.randn(n, cout, d // 2, h // 2, w // 2, generator=g)
+    x = ops.as_input(xv.to(DEV), dt)
+    dy1 = ops.as_input(g1.to(DEV), dt)
+    dy2 = ops.as_input(g2.to(DEV), dt)
+    both = ops.conv_wgrad_pair(x, dy1, dy2, 2)
+    assert both is not None, "no fused kernel for %s" % (dims,)
+    gw3, gw1 = both
+    assert torch.equal(gw3, ops.conv_wgrad(x, dy1, 3, 2)), "3x3x3 part differs from the plain stride-2 kernel"
+    ref1 = torch.nn.grad.conv3d_weight(_rt(xv, dt), (cout, cin, 1, 1, 1), _rt(g2, dt), stride=2)
+    _close(gw1, ref1, 2e-3, 1e-3, "1x1x1 stride-2 weight gradient from the pair kernel %s %s" % ((cin, cout), dims))
+    _close(gw1, ops.conv_wgrad(x, dy2, 1, 2), 1e-4, 1e-4, "pair vs staged 1x1x1 stride-2 weight gradient")
