@@ -322,7 +322,8 @@ bool wgrad_slide_plan(const WgradGeom& g, WgradSlidePlan* out) {
     // buffer-descriptor byte offsets of a sample, the top bit marking "outside the volume"
     if ((int64_t)g.Do * g.Ho * g.Wo * (g.ldx > g.lddy ? g.ldx : g.lddy) >= (1ll << 30)) return false;
     const int pairs = (g.Cin / 32) * (g.Cout / 32);
-    if (pairs > 16) return false;      // up to 128 -> 128 channels (round 3: 8 -> 16 pairs, 89 -> 62 us at 32^3)
+    static const int max_pairs = getenv("RU3D_WGRAD_SLIDE_PAIRS") ? atoi(getenv("RU3D_WGRAD_SLIDE_PAIRS")) : 32;
+    if (pairs > max_pairs) return false;      // up to 256 -> 128 channels (round 3: 8 -> 16 pairs, 89 -> 62 us at 32^3)
     const int tw_n = (g.Wo + TW - 1) / TW;
     const bool light = (g.Wo % TW) != 0 && (g.Wo % TW) <= 16 && tw_n > 1;
     const int64_t cols = (int64_t)g.N * (g.Ho / TH) * tw_n;
