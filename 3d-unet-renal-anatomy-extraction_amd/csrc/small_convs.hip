@@ -229,9 +229,19 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, 
         for (int i = 0; i < VEC; i++)
 #pragma unroll
             for (int c = 0; c < 4; c++) acc[c] = fmaf(xv[u][i], wr[i][c], acc[c]);
-        for (int o = 1; o < G; o <<= 1) {
+        if (G == 4) {
+            // a voxel's four lanes are a DPP quad: the two butterfly steps as quad permutes (same pairs, same sums as the
+            // xor-shuffles, which are LDS-crossbar instructions: 8 per voxel and lane)
 #pragma unroll
-            for (int c = 0; c < 4; c++) acc[c] += __shfl_xor(acc[c], o, 64);
+            for (int c = 0; c < 4; c++) {
+                acc[c] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc[c]), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+                acc[c] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(acc[c]), 0x4E, 0xf, 0xf, true));   // lane ^ 2
+            }
+        } else {
+            for (int o = 1; o < G; o <<= 1) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) acc[c] += __shfl_xor(acc[c], o, 64);
+            }
         }
         const int64_t vo = v0 + u * slots;
         if (vo < total) {
