@@ -566,20 +566,45 @@ __device__ __forceinline__ void wgrad_reduce_tiled_body(const float* __restrict_
     const int64_t total = (int64_t)taps * cin * cout;
     const int nquads = taps * 32;   // (tap, ci_l, co4)
     const int pitch_co = 4 * taps + 1;
-#pragma unroll 1
-    for (int qid = threadIdx.x; qid < nquads; qid += 256) {
+    // a thread's (up to) four quads side by side: 16 row reads in flight instead of 4 - with 128 blocks of 221 KB each at
+    // 128 x 128 channels the kernel ran at the latency of its loads (29 us for 28 MB that sit in L2).  Per quad the same
+    // four partial sums in the same order as before (c mod 4, then (s0 + s1) + (s2 + s3)): bit-identical results.
+    constexpr int QPT = 4;      // 27 taps x 32 quads = 864 <= 4 x 256
+    const float* src[QPT];
+    bool live[QPT];
+    f32x4 acc[QPT][4];
+#pragma unroll
+    for (int k = 0; k < QPT; k++) {
+        const int qid = threadIdx.x + 256 * k;
+        live[k] = qid < nquads;
+        const int qq = live[k] ? qid : 0;
+        const int tap = qq >> 5, ci_l = (qq >> 3) & 3, co4 = qq & 7;
+        src[k] = part + ((int64_t)tap * cin + ci0 + ci_l) * cout + co0 + co4 * 4;
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[k][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    int c = 0;
+    for (; c + 3 < chunks; c += 4) {
+        f32x4 v[QPT][4];
+#pragma unroll
+        for (int k = 0; k < QPT; k++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[k][j] = *reinterpret_cast<const f32x4*>(src[k] + (int64_t)(c + j) * total);
+#pragma unroll
+        for (int k = 0; k < QPT; k++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[k][j] += v[k][j];
+    }
+    for (; c < chunks; c++) {
+#pragma unroll
+        for (int k = 0; k < QPT; k++) acc[k][0] += *reinterpret_cast<const f32x4*>(src[k] + (int64_t)c * total);
+    }
+#pragma unroll
+    for (int k = 0; k < QPT; k++) {
+        if (!live[k]) continue;
+        const int qid = threadIdx.x + 256 * k;
         const int tap = qid >> 5, ci_l = (qid >> 3) & 3, co4 = qid & 7;
-        const float* src = part + ((int64_t)tap * cin + ci0 + ci_l) * cout + co0 + co4 * 4;
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-        int c = 0;
-        for (; c + 3 < chunks; c += 4) {
-            s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)c * total);
-            s1 += *reinterpret_cast<const f32x4*>(src + (int64_t)(c + 1) * total);
-            s2 += *reinterpret_cast<const f32x4*>(src + (int64_t)(c + 2) * total);
-            s3 += *reinterpret_cast<const f32x4*>(src + (int64_t)(c + 3) * total);
-        }
-        for (; c < chunks; c++) s0 += *reinterpret_cast<const f32x4*>(src + (int64_t)c * total);
-        const f32x4 s = (s0 + s1) + (s2 + s3);
+        const f32x4 s = (acc[k][0] + acc[k][1]) + (acc[k][2] + acc[k][3]);
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const int co = co4 * 4 + e;
