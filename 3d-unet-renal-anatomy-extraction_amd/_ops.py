@@ -848,7 +848,11 @@ def as_grad(g, like_dtype):
 # size: RU3D_WGRAD_STREAM = 0 never, 1 always, unset: when a block's tensors have at most RU3D_SIDE_MAXVOX voxels in all
 # (default 65536 = the 32^3 level at batch 2: 17.10 -> 16.92 ms same box; with the 16^3 / 8^3 levels alone 17.10 -> 17.11 -
 # their kernels are bound by the CUs' L1 / LDS paths, which a concurrent kernel shares).
-_SIDE_MODE = os.environ.get("RU3D_WGRAD_STREAM", "auto")
+# End of round 4: OFF by default.  With the launch count down from 596 to 385 and the skip convs' weight gradients riding in
+# their partners' kernels, the overlap no longer pays for itself: captured step 15.42 (auto) vs 15.38 ms (off), eager loop
+# 15.63 vs 15.40 ms - the fork / join calls cost the host-bound eager loop more than the overlap returns (same box, three
+# rounds each).  RU3D_WGRAD_STREAM=auto / 1 bring it back.
+_SIDE_MODE = os.environ.get("RU3D_WGRAD_STREAM", "0")
 _SIDE_MAXVOX = int(os.environ.get("RU3D_SIDE_MAXVOX", "65536"))
 _SIDE = {}
 _SIDE_BUSY = {}      # device -> tensors the side stream still reads (kept alive until the join)

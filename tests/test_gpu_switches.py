@@ -23,7 +23,7 @@ SWITCHES = {
     "in": [{"RU3D_CONV_S2": "0", "RU3D_FUSED_SKIP": "0", "RU3D_DGRAD_PAIR": "0"},       # round-2 direct forms, unfused tails
            {"RU3D_CONV_SLIDE64": "0", "RU3D_WGRAD_SLIDE": "0", "RU3D_CONV_PC": "0"},    # no sliding 64-channel / wgrad kernels
            {"RU3D_CONV_WS": "2", "RU3D_STEM_MFMA": "0", "RU3D_HEAD_FUSED": "0"},         # whole-sample conv, VALU stem, unfused head backward
-           {"RU3D_SKIP_LINK": "0", "RU3D_WGRAD_DIRECT": "0", "RU3D_WGRAD_STREAM": "0"},  # concat copies, slabs at 8^3, one stream
+           {"RU3D_SKIP_LINK": "0", "RU3D_WGRAD_DIRECT": "0", "RU3D_WGRAD_STREAM": "auto", "RU3D_WGRAD_PAIR": "0"},  # concat copies, slabs at 8^3, weight gradients of the small levels on a second stream, skip-conv weight gradients as launches of their own
            # round 4: norm.hip's three launches on the small levels, the interleaved concat on the full-resolution level
            # ... and the deep levels on the 1 x 2-accumulator conv kernel instead of the split-in-workgroup one
            {"RU3D_IN_SMALL": "0", "RU3D_PLANAR_CONCAT": "0", "RU3D_CONV_SK": "0"}],
